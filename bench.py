@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""bench.py -- decompressed GiB/s (and % of HBM roofline) of the batched DEFLATE
+extract path on MI355X: BASELINE.json's metric on its configs[1]
+(10 000 synthetic enwik-style 64 KiB entries, zlib level 6, one archive image).
+
+One "step" = one pass of the hot path over the whole batch:
+ozg_decode_batch_device_ex() on an archive image, descriptor table and output
+arena that are already resident in HBM (the PCIe-inclusive rate is reported
+separately in DESIGN.md; it is never `value`).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: entries are independent, so each rank decodes its own 10 000-entry
+shard of one N x 10 000-entry job (weak scaling, no data-path collective; RCCL is
+only used for the barrier and the max-over-ranks timing).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+import zlib
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW" (spec)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def load_shard(rank, n, size, method, cache_dir):
+    """The rank's archive image + entry table, cached on local disk between runs."""
+    import numpy as np
+    from otezip_amd import corpus
+    os.makedirs(cache_dir, exist_ok=True)
+    tag = "m%d_n%d_s%d_r%d_v2" % (method, n, size, rank)
+    p_arc, p_ent = os.path.join(cache_dir, tag + ".zip"), os.path.join(cache_dir, tag + ".npy")
+    if os.path.exists(p_arc) and os.path.exists(p_ent):
+        with open(p_arc, "rb") as f:
+            arc = f.read()
+        ent = np.load(p_ent)
+        return arc, ent
+    t0 = time.time()
+    arc, entries = corpus.build_archive(n, size, methods=(method,), first=rank * n)
+    ent = np.array([(e["method"], e["data_off"], e["comp_size"], e["uncomp_size"], e["crc32"]) for e in entries],
+                   dtype=np.int64)
+    log("[bench] rank %d generated %d entries in %.1fs" % (rank, n, time.time() - t0))
+    tmp = p_arc + ".tmp%d" % os.getpid()
+    with open(tmp, "wb") as f:
+        f.write(arc)
+    os.replace(tmp, p_arc)
+    np.save(p_ent + ".tmp%d.npy" % os.getpid(), ent)
+    os.replace(p_ent + ".tmp%d.npy" % os.getpid(), p_ent)
+    return arc, ent
+
+
+def cpu_baseline(arc, ent, sample_entries):
+    """Reference (oracle/_ref/ref_bench, built from /root/reference in the build container)
+    timed on this box's host cores over the first `sample_entries` entries of the same
+    archive; N workers with independent zip_t handles, entries i mod N.
+    Falls back to the oracle restatement ("port", 1 core) when the reference build did not travel."""
+    from otezip_amd import corpus  # noqa: F401
+    cores = min(os.cpu_count() or 1, 16)
+    ref_bench = os.path.join(ROOT, "oracle", "_ref", "ref_bench")
+    n = min(sample_entries, len(ent))
+    if os.path.exists(ref_bench):
+        with tempfile.NamedTemporaryFile(suffix=".zip", delete=False, dir="/tmp") as f:
+            f.write(arc)
+            path = f.name
+        try:
+            t0 = time.time()
+            procs = [subprocess.Popen([ref_bench, path, str(i), str(cores), str(n)], stdout=subprocess.PIPE,
+                                      stderr=subprocess.DEVNULL) for i in range(cores)]
+            outs = [p.communicate(timeout=600)[0].decode().split() for p in procs]
+            wall = time.time() - t0
+        finally:
+            os.unlink(path)
+        nbytes = sum(int(o[1]) for o in outs)
+        nulls = sum(int(o[3]) for o in outs)
+        worker_max = max(float(o[2]) for o in outs)
+        return {"value": nbytes / worker_max / 2**30, "unit": "GiB/s", "cores": cores, "kind": "reference",
+                "sample": "first %d of the same 64 KiB DEFLATE entries, zip_fopen_index+zip_fclose, %d processes "
+                          "x independent zip_open, wall %.1fs, reference NULL entries %d" % (n, cores, wall, nulls)}
+    from oracle import pyoracle as O
+    n = min(n, 200)
+    t0 = time.time()
+    nbytes = 0
+    for m, off, cs, us, crc in ent[:n]:
+        r = O.extract_entry(int(m), arc[off:off + cs], int(us), int(crc))
+        nbytes += len(r["out"])
+    dt = time.time() - t0
+    return {"value": nbytes / dt / 2**30, "unit": "GiB/s", "cores": 1, "kind": "port",
+            "sample": "first %d entries through the C restatement oracle/otz_oracle.c (reference build absent)" % n}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--entries", type=int, default=10000, help="entries per GPU")
+    ap.add_argument("--entry-size", type=int, default=65536)
+    ap.add_argument("--method", type=int, default=8)
+    ap.add_argument("--cpu-sample", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cache-dir", default=os.environ.get("OTEZIP_BENCH_CACHE", "/tmp/otezip_amd_cache"))
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log("[bench] WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import otezip_amd as oz
+    from otezip_amd import _native as N
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: otezip-amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    oz.init(local_rank)
+    L = oz.lib()
+
+    arc, ent = load_shard(rank, args.entries, args.entry_size, args.method, args.cache_dir)
+    n = len(ent)
+    items = [(int(m), int(off), int(cs), int(us), int(crc)) for m, off, cs, us, crc in ent]
+    ents, dst_len = oz.make_entries(items)
+    comp_bytes = int(ent[:, 2].sum())
+    out_bytes = int(ent[:, 3].sum())
+
+    d_src = torch.frombuffer(bytearray(arc), dtype=torch.uint8).to(dev)
+    d_dst = torch.empty(dst_len + 64, dtype=torch.uint8, device=dev)
+    d_ent = torch.frombuffer(bytearray(bytes(ents)), dtype=torch.uint8).to(dev)
+    d_res = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream()
+    flags = oz.BATCH_ONLY_DEFLATE if args.method == 8 else oz.BATCH_NO_DEFLATE
+
+    def step():
+        N.check(L.ozg_decode_batch_device_ex(d_src.data_ptr(), d_src.numel(), d_dst.data_ptr(), d_dst.numel(),
+                                             d_ent.data_ptr(), d_res.data_ptr(), n, stream.cuda_stream, flags), "decode")
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record(stream)
+        step()
+        b.record(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = [a.elapsed_time(b) for a, b in evs]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # every entry must have decoded and must match the directory CRC
+    res = np.frombuffer(d_res.cpu().numpy().tobytes(), dtype=np.int32).reshape(n, 4)
+    bad = int((res[:, 0] != oz.ST_OK).sum())
+    crc_bad = int(((res[:, 3].astype(np.uint32) & oz.F_CRC_MISMATCH) != 0).sum())
+    f2 = int(((res[:, 3].astype(np.uint32) & oz.F_REF_FALSE_REJECT) != 0).sum())
+    # and a sample is compared byte for byte with an independent decoder (host zlib)
+    host = d_dst.cpu().numpy()
+    mism = 0
+    for i in range(0, n, max(1, n // 64)):
+        m, off, cs, us, crc = items[i]
+        want = zlib.decompress(arc[off:off + cs], -15) if m == 8 else None
+        if want is not None and host[ents[i].dst_off:ents[i].dst_off + us].tobytes() != want:
+            mism += 1
+    if bad or crc_bad or mism:
+        raise SystemExit("[bench] INVALID RUN: %d entries failed, %d CRC mismatches, %d byte mismatches" %
+                         (bad, crc_bad, mism))
+
+    ok = torch.tensor([1.0], device=dev)
+    if world > 1:
+        dist.all_reduce(ok)
+    if rank == 0:
+        total_out = out_bytes * world  # every rank decodes a shard of the same shape
+        value = total_out * args.steps / elapsed / 2**30
+        kavg = sum(kernel_ms) / len(kernel_ms) * 1e-3
+        algo = comp_bytes + out_bytes
+        line = {
+            "metric": "decompressed GiB/s, batched DEFLATE extract (zip_fopen_index path), 64 KiB entries",
+            "value": round(value, 3), "unit": "GiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "configs[1]: %d x %d B enwik-style entries per GPU, zlib-6 raw DEFLATE, ratio %.2f, "
+                                   "one ZIP32 archive image resident in HBM" % (n, args.entry_size, out_bytes / comp_bytes),
+                       "entries_per_gpu": n, "entry_bytes": args.entry_size, "method": args.method,
+                       "parallelism": "entries sharded %d-way, no data-path collective" % world,
+                       "ref_false_rejects": f2},
+            "roofline": {"bound": "hbm", "achieved": round(algo / kavg / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": round(algo / kavg / HBM_PEAK, 5), "traffic": None,
+                         "kernel": N.lib().ozg_kernel_name_inflate().decode() if args.method == 8 else
+                         N.lib().ozg_kernel_name_copy().decode(),
+                         "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(kavg * 1e3, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(arc, ent, args.cpu_sample)
+            except Exception as ex:  # the baseline is a report, never a reason to lose the GPU number
+                line["cpu_baseline"] = {"value": None, "unit": "GiB/s", "cores": 0, "kind": "reference",
+                                        "sample": "failed: %r" % (ex,)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    oz.shutdown()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,139 @@
+/* otezip_gpu.h -- C ABI between plain-C host code and the HIP (gfx950) codec
+ * kernels of otezip-amd.  Plain pointers and sizes only; no C++ / torch types.
+ *
+ * What it replaces.  otezip decodes one entry per call inside
+ * otezip_extract_entry() (ref src/lib/otezip.c:399-684): read the compressed
+ * bytes, switch on the ZIP method, run the codec with Z_FINISH into a zeroed
+ * buffer of uncomp_size bytes, CRC-32 the result.  ozg_decode_batch_* is that
+ * function from ":479 switch(method)" to ":679 CRC check", for N independent
+ * entries in one launch.  ozg_encode_batch_* is otezip_compress_data()
+ * (ref src/lib/otezip.c:788-1076) plus the CRC of zip_file_add (:1124).
+ *
+ * Entry points a binding needs (the reference is C, so the "FFI" is a plain
+ * declaration + link against libotezip_amd.so):
+ *   ozg_init / ozg_shutdown / ozg_last_error
+ *   ozg_decode_batch_device   device-resident src/dst/tables, async on a stream
+ *   ozg_decode_batch_device_ex  same, with a method-mix hint
+ *   ozg_decode_batch_host     host buffers; stages over PCIe and waits
+ *   ozg_crc32_batch_device    otezip_crc32 (ref src/lib/crc32.inc.c:40-47) x N
+ *   ozg_malloc / ozg_free / ozg_memcpy_* / ozg_stream_sync   so that host C
+ *                             code needs no HIP headers
+ */
+#ifndef OTEZIP_GPU_H
+#define OTEZIP_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* library-level return codes */
+#define OZG_OK 0
+#define OZG_E_NODEVICE (-1) /* no HIP device / runtime: there is NO CPU fallback */
+#define OZG_E_ARG (-2)
+#define OZG_E_HIP (-3) /* a HIP call failed; see ozg_last_error() */
+#define OZG_E_NOMEM (-4)
+
+/* per-entry status: the zlib-style code the reference codec returns for the
+ * entry (ref src/lib/deflate.inc.c:35-43), with the premature Z_BUF_ERROR of
+ * the reference's inflate repaired (parity rule 2). */
+#define OZG_ST_OK 1          /* Z_STREAM_END: dst[0..uncomp_size) is the entry */
+#define OZG_ST_NEED_OUT 0    /* Z_OK: stream produces more than uncomp_size bytes */
+#define OZG_ST_DATA (-3)     /* Z_DATA_ERROR: malformed stream */
+#define OZG_ST_BUF (-5)      /* Z_BUF_ERROR: stream truncated */
+#define OZG_ST_SIZE (-20)    /* codec ended but total_out != uncomp_size (ref :555, :584, :625, :654),
+                                or STORE with comp_size != uncomp_size (:482) */
+#define OZG_ST_BOMB (-21)    /* expansion guard, ref :454-462 */
+#define OZG_ST_METHOD (-22)  /* unsupported method, ref :662-665 */
+#define OZG_ST_INTERNAL (-30)
+
+/* result flags */
+#define OZG_F_REF_FALSE_REJECT 1u /* valid DEFLATE stream the reference itself rejects (F2) */
+#define OZG_F_SHORT_STREAM 2u     /* DEFLATE ended early; tail zero-filled as the reference does (F12) */
+#define OZG_F_CRC_MISMATCH 4u     /* crc32 != expected (ref :669) */
+
+/* entry flags (in) */
+#define OZG_EF_IGNORE_ZIPBOMB 1u /* mirrors the global otezip_ignore_zipbomb */
+
+#define OZG_METHOD_STORE 0
+#define OZG_METHOD_DEFLATE 8
+#define OZG_METHOD_LZMA 14
+#define OZG_METHOD_ZSTD 93
+#define OZG_METHOD_BROTLI 97
+#define OZG_METHOD_LZFSE 100
+
+/* One archive entry to decode: the fields of struct otezip_entry
+ * (ref src/include/otezip/zip.h:78-88) the decode path reads, with file
+ * offsets replaced by offsets into the caller's src/dst buffers. 32 bytes. */
+typedef struct ozg_entry {
+	uint64_t src_off;     /* compressed payload: src + src_off, any alignment */
+	uint64_t dst_off;     /* output: dst + dst_off, MUST be a multiple of 16 */
+	uint32_t comp_size;
+	uint32_t uncomp_size; /* output capacity == the avail_out the reference passes (:507) */
+	uint32_t crc32;       /* directory CRC-32 to compare with */
+	uint16_t method;
+	uint16_t flags;       /* OZG_EF_* */
+} ozg_entry;
+
+/* 16 bytes */
+typedef struct ozg_result {
+	int32_t status;     /* OZG_ST_* */
+	uint32_t total_out; /* bytes the codec produced */
+	uint32_t crc32;     /* CRC-32 of dst[0..uncomp_size) when status == OZG_ST_OK */
+	uint32_t flags;     /* OZG_F_* */
+} ozg_result;
+
+/* Tunables mirrored from the reference's globals (ref src/lib/otezip.c:157-166). */
+typedef struct ozg_limits {
+	uint64_t max_expansion_ratio; /* default 1000 */
+	uint64_t max_expansion_slack; /* default 1 MiB */
+} ozg_limits;
+
+int ozg_init(int device);
+void ozg_shutdown(void);
+const char *ozg_last_error(void);
+int ozg_device_count(void);
+void ozg_set_limits(const ozg_limits *lim);
+
+/* All pointers are device pointers; the call only enqueues work on `stream`
+ * (a hipStream_t passed as void*, NULL = default stream).  dst regions of
+ * different entries must not overlap; each needs uncomp_size bytes rounded up
+ * to 16.  Entries whose status != OZG_ST_OK leave their dst region undefined. */
+int ozg_decode_batch_device(const void *d_src, uint64_t src_len, void *d_dst, uint64_t dst_len,
+	const ozg_entry *d_entries, ozg_result *d_results, uint32_t n, void *stream);
+
+/* Same, with a hint about the method mix so that a launch can be skipped when
+ * the caller (who parsed the central directory) knows it is not needed. */
+#define OZG_BATCH_ONLY_DEFLATE 1u /* every entry is method 8: skip the copy kernel */
+#define OZG_BATCH_NO_DEFLATE 2u   /* no entry is method 8: skip the inflate kernel */
+int ozg_decode_batch_device_ex(const void *d_src, uint64_t src_len, void *d_dst, uint64_t dst_len,
+	const ozg_entry *d_entries, ozg_result *d_results, uint32_t n, void *stream, uint32_t batch_flags);
+
+/* Same with host buffers: copies src and the tables to the device, runs the
+ * batch, copies dst and results back, and waits. */
+int ozg_decode_batch_host(const void *src, uint64_t src_len, void *dst, uint64_t dst_len,
+	const ozg_entry *entries, ozg_result *results, uint32_t n);
+
+/* crc[i] = CRC-32 of d_buf[off[i] .. off[i]+len[i]) (all device pointers). */
+int ozg_crc32_batch_device(const void *d_buf, const uint64_t *d_off, const uint32_t *d_len, uint32_t *d_crc,
+	uint32_t n, void *stream);
+
+/* thin wrappers so a C host needs no HIP headers */
+void *ozg_malloc(size_t bytes);
+void ozg_free(void *d_ptr);
+void *ozg_malloc_pinned(size_t bytes);
+void ozg_free_pinned(void *h_ptr);
+int ozg_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
+int ozg_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
+int ozg_stream_sync(void *stream);
+
+/* Names of the kernels a profiler will show, for tooling. */
+const char *ozg_kernel_name_inflate(void);
+const char *ozg_kernel_name_copy(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,1135 @@
+// otz_inflate.h -- raw DEFLATE (RFC 1951) decode of ONE archive entry by ONE
+// 256-lane workgroup.  Replaces inflateInit2(-15)/inflate(Z_FINISH)/inflateEnd
+// as otezip_extract_entry drives them (ref src/lib/otezip.c:490-532,
+// src/lib/deflate-dec.inc.c:452-518, :547-831) plus the CRC-32 of :668.
+//
+// The reference walks the stream one bit at a time and searches every symbol
+// per bit.  A wavefront cannot win that way, so the work is reorganised:
+//
+//   * the entry's whole output lives in a 64 KiB LDS ring (the 32 KiB LZ77
+//     window never touches HBM); it is flushed with coalesced 16-byte stores
+//     and the CRC is taken from LDS on the way out;
+//   * Huffman decode is parallel INSIDE the stream: each round stages 4 KiB of
+//     compressed bytes into LDS (coalesced 16-byte loads), every lane decodes
+//     the 128-bit subsequence that starts at its own speculative bit offset
+//     (pass A), then re-decodes from where its left neighbour really ended
+//     until it meets its own pass-A token boundaries (pass B; prefix codes
+//     self-synchronise within a few tokens).  A fixpoint over the per-lane
+//     exit positions yields the true token chain; a workgroup prefix sum of
+//     per-lane output bytes places every lane's tokens;
+//   * literals and LZ77 copies are written by all lanes at once (pass C); a
+//     copy whose source bytes are not final yet waits on a per-byte "final"
+//     bitmap in LDS instead of on program order.
+//
+// Results are bit-identical to a correct inflate; where the reference itself
+// misbehaves the rules of SURVEY.md section 8 apply (F2 repaired and flagged,
+// F12 zero-fill mirrored, malformed streams fail cleanly).
+//
+// Deliberate difference on MALFORMED input only: an over-subscribed Huffman
+// code set is rejected (Z_DATA_ERROR) instead of being decoded by the
+// reference's first-match search (ref :671-691); parity rule 4.
+#pragma once
+
+#include "otz_simt.h"
+#include "otz_crc.h"
+#include "../../include/otezip_gpu.h"
+
+#define OTZ_NT 256u
+#define OTZ_RING 65536u
+#define OTZ_RING_MASK 65535u
+#define OTZ_S_BITS 128u         // speculative subsequence per lane per round
+#define OTZ_TOK_CAP 32u         // tokens per pass-A path (bounds lane 0's output)
+#define OTZ_RMAX 16384u         // output bytes per round (size of the final bitmap)
+#define OTZ_STAGE_BYTES 4608u   // 256 lanes * 16 B + skew + lookahead; also holds the CRC tables
+#define OTZ_STAGE_WORDS (OTZ_STAGE_BYTES / 4)
+#define OTZ_LIT_ROOT 10
+#define OTZ_DIST_ROOT 8
+#define OTZ_SPIN_LIMIT 4000000u
+#define OTZ_ST_NEED_OUT_INT (-100) // OZG_ST_NEED_OUT is 0, which L.status uses for "still decoding"
+
+// exit word of a lane's path: [23:0] stage-relative bit position, [26:24] kind
+#define OTZ_X_NORMAL 0u  // first token start at or beyond the lane's range
+#define OTZ_X_EOB 1u     // position just after an end-of-block code
+#define OTZ_X_CUT 2u     // stopped after OTZ_TOK_CAP tokens
+#define OTZ_X_INVALID 3u // no code matches / reserved symbol
+#define OTZ_X_TRUNC 4u   // ran past the end of the input
+#define OTZ_X_DEAD 5u    // left neighbour's path terminated: not on the chain
+#define OTZ_X_POS(x) ((x) & 0xFFFFFFu)
+#define OTZ_X_KIND(x) ((x) >> 24)
+#define OTZ_X_MAKE(kind, pos) (((kind) << 24) | (pos))
+
+// LUT entry: [3:0] code length (0 = longer than the root, or no code),
+// [5:4] kind, [11:8] extra-bit count, [31:16] literal / base length / base distance
+#define OTZ_K_LIT 0u
+#define OTZ_K_LEN 1u
+#define OTZ_K_EOB 2u
+#define OTZ_K_BAD 3u
+
+struct otz_canon {
+	u16 first[16]; // first code value of each length
+	u16 count[16];
+	u16 off[16];   // index of the first symbol of each length in sorted[]
+};
+
+struct otz_inflate_lds {
+	u8 ring[OTZ_RING];
+	u32 lit_lut[1u << OTZ_LIT_ROOT];
+	u32 dist_lut[1u << OTZ_DIST_ROOT];
+	u16 lit_sorted[288];
+	u16 dist_sorted[32];
+	otz_canon lit_c, dist_c, cl_c;
+	u8 cl_sorted[20];
+	u8 cl_len[20];
+	u32 cl_lut[128];
+	union {
+		u32 stage_w[OTZ_STAGE_WORDS];
+		u8 stage[OTZ_STAGE_BYTES];
+		u32 crc_t4[1024];
+	};
+	union {
+		u32 fin[OTZ_RMAX / 32]; // pass C: byte is final
+		u32 exits[OTZ_NT];      // pass A/B: per-lane exit word
+		u8 ll[320];             // table build: code lengths
+	};
+	u32 hist[16 * 2]; // code length histograms (lit, dist)
+	u32 scan[8];      // per-wave partials
+	// workgroup-uniform scalars
+	u32 status;       // 0 while decoding, else (u32) final status code (nonzero ends the entry)
+	u32 flag;
+	u32 first_term;
+	u32 first_rej;
+	u32 next_start;
+	u32 hdr_bits;     // header: bits consumed
+	u32 hlit, hdist;
+	u32 bfinal, btype;
+	u32 stored_len;
+	u32 eob_start_lo, eob_start_hi;
+	u32 rej_bytes_incl;
+	u32 acc_bytes;
+};
+
+struct otz_job {
+	const u8 *in;
+	u32 n_in;
+	u8 *out;
+	u32 out_cap;
+};
+
+// ------------------------------------------------------------------ helpers
+
+OTZ_DEV void otz_set_status(otz_inflate_lds &L, int st) { otz_lds_store (&L.status, (u32)st); }
+OTZ_DEV int otz_get_status(const otz_inflate_lds &L) { return (int)otz_lds_load (&L.status); }
+
+OTZ_DEV u32 otz_mk_lit_entry(u32 sym, u32 len) {
+	if (sym < 256u) {
+		return (sym << 16) | (OTZ_K_LIT << 4) | len;
+	}
+	if (sym == 256u) {
+		return (OTZ_K_EOB << 4) | len;
+	}
+	if (sym > 285u) {
+		return (OTZ_K_BAD << 4) | len; // ref deflate-dec.inc.c:794-797
+	}
+	u32 k = sym - 257u, base, xb;
+	if (k < 8u) {
+		base = 3u + k;
+		xb = 0;
+	} else if (k == 28u) {
+		base = 258u;
+		xb = 0;
+	} else {
+		xb = (k >> 2) - 1u;
+		base = 3u + ((4u + (k & 3u)) << xb);
+	}
+	return (base << 16) | (xb << 8) | (OTZ_K_LEN << 4) | len;
+}
+
+OTZ_DEV u32 otz_mk_dist_entry(u32 sym, u32 len) {
+	if (sym >= 30u) {
+		return (OTZ_K_BAD << 4) | len; // reference indexes past dist_base[] here (:766-774)
+	}
+	u32 base, xb;
+	if (sym < 4u) {
+		base = 1u + sym;
+		xb = 0;
+	} else {
+		xb = (sym >> 1) - 1u;
+		base = 1u + ((2u + (sym & 1u)) << xb);
+	}
+	return (base << 16) | (xb << 8) | (OTZ_K_LEN << 4) | len;
+}
+
+// canonical decode of the code that starts at the low bits of `bits`
+// (stream order, LSB first), trying lengths lo..hi
+OTZ_DEV u32 otz_canon_lookup(const otz_canon &c, u32 bits, u32 lo, u32 hi, u32 *len_out) {
+	u32 rev = otz_brev (bits);
+	for (u32 l = lo; l <= hi; l++) {
+		u32 code = rev >> (32u - l);
+		u32 idx = code - (u32)c.first[l];
+		if (idx < (u32)c.count[l]) {
+			*len_out = l;
+			return (u32)c.off[l] + idx;
+		}
+	}
+	*len_out = 0;
+	return 0;
+}
+
+struct otz_br {
+	u64 bb;
+	u32 bc;
+	u32 nw;
+};
+
+OTZ_DEV void otz_br_init(otz_br &r, const u32 *sw, u32 bitpos) {
+	u32 w = bitpos >> 5, s = bitpos & 31u;
+	r.bb = (u64) (sw[w] >> s);
+	r.bc = 32u - s;
+	r.nw = w + 1u;
+}
+OTZ_DEV void otz_br_refill(otz_br &r, const u32 *sw) {
+	if (r.bc <= 32u) {
+		u32 w = r.nw < OTZ_STAGE_WORDS ? sw[r.nw] : 0u;
+		r.bb |= (u64)w << r.bc;
+		r.bc += 32u;
+		r.nw++;
+	}
+}
+OTZ_DEV void otz_br_drop(otz_br &r, u32 n) {
+	r.bb >>= n;
+	r.bc -= n;
+}
+
+struct otz_tok {
+	u32 kind;  // OTZ_K_*
+	u32 nbits; // stream bits of the whole token
+	u32 val;   // literal byte or match length
+	u32 dist;
+};
+
+// Decode one token (literal / end-of-block / length+distance pair).
+OTZ_DEV otz_tok otz_decode_token(const otz_inflate_lds &L, otz_br &r) {
+	otz_tok t;
+	otz_br_refill (r, L.stage_w);
+	u32 lo = (u32)r.bb;
+	u32 e = L.lit_lut[lo & ((1u << OTZ_LIT_ROOT) - 1u)];
+	if ((e & 15u) == 0u) {
+		u32 l;
+		u32 i = otz_canon_lookup (L.lit_c, lo, OTZ_LIT_ROOT + 1, 15, &l);
+		e = l ? otz_mk_lit_entry (L.lit_sorted[i], l) : (OTZ_K_BAD << 4);
+	}
+	u32 len = e & 15u;
+	t.kind = (e >> 4) & 3u;
+	t.val = e >> 16;
+	t.dist = 0;
+	t.nbits = len;
+	if (t.kind != OTZ_K_LEN) {
+		otz_br_drop (r, len);
+		return t;
+	}
+	u32 xb = (e >> 8) & 15u;
+	t.val += (u32) (r.bb >> len) & ((1u << xb) - 1u);
+	otz_br_drop (r, len + xb);
+	otz_br_refill (r, L.stage_w);
+	lo = (u32)r.bb;
+	u32 d = L.dist_lut[lo & ((1u << OTZ_DIST_ROOT) - 1u)];
+	if ((d & 15u) == 0u) {
+		u32 l;
+		u32 i = otz_canon_lookup (L.dist_c, lo, OTZ_DIST_ROOT + 1, 15, &l);
+		d = l ? otz_mk_dist_entry (L.dist_sorted[i], l) : (OTZ_K_BAD << 4);
+	}
+	u32 dl = d & 15u, dxb = (d >> 8) & 15u;
+	if (((d >> 4) & 3u) != OTZ_K_LEN) {
+		t.kind = OTZ_K_BAD;
+		return t;
+	}
+	t.dist = (d >> 16) + ((u32) (r.bb >> dl) & ((1u << dxb) - 1u));
+	otz_br_drop (r, dl + dxb);
+	t.nbits = len + xb + dl + dxb;
+	return t;
+}
+
+// Inclusive prefix sum over the workgroup; *total gets the sum. Uniform control flow.
+OTZ_DEV u32 otz_block_scan_incl(u32 v, u32 *scratch, u32 *total) {
+	u32 lane = otz_lane ();
+#pragma unroll
+	for (u32 d = 1; d < 64; d <<= 1) {
+		u32 o = otz_shfl_up (v, d);
+		if (lane >= d) {
+			v += o;
+		}
+	}
+	otz_sync ();
+	if (lane == 63u) {
+		scratch[otz_wave ()] = v;
+	}
+	otz_sync ();
+	u32 add = 0, tot = 0;
+	for (u32 w = 0; w < OTZ_NT / 64; w++) {
+		u32 s = scratch[w];
+		if (w < otz_wave ()) {
+			add += s;
+		}
+		tot += s;
+	}
+	*total = tot;
+	return v + add;
+}
+
+// ------------------------------------------------------- staging compressed bytes
+
+// Stage OTZ_STAGE_BYTES of input starting at the 16-byte-aligned global address at
+// or below in+byte0; zero beyond the entry. Returns the skew (in+byte0 - aligned).
+OTZ_DEV u32 otz_stage_load(otz_inflate_lds &L, const otz_job &J, u32 byte0) {
+	const u8 *p = J.in + byte0;
+	u32 skew = (u32) ((uintptr_t)p & 15u);
+	const u8 *ga = p - skew;
+	const u8 *lo = J.in, *hi = J.in + J.n_in;
+	for (u32 c = otz_tid (); c < OTZ_STAGE_BYTES / 16; c += OTZ_NT) {
+		const u8 *a = ga + 16u * c;
+		otz_u4 v;
+		if (a >= lo && a + 16 <= hi) {
+			v = otz_ld16_aligned (a);
+		} else {
+			u32 w[4] = { 0, 0, 0, 0 };
+			if (a + 16 > lo && a < hi) {
+				for (u32 k = 0; k < 16; k++) {
+					const u8 *q = a + k;
+					if (q >= lo && q < hi) {
+						w[k >> 2] |= (u32)*q << (8u * (k & 3u));
+					}
+				}
+			}
+			v.x = w[0];
+			v.y = w[1];
+			v.z = w[2];
+			v.w = w[3];
+		}
+		u32 *d = &L.stage_w[4u * c];
+		d[0] = v.x;
+		d[1] = v.y;
+		d[2] = v.z;
+		d[3] = v.w;
+	}
+	return skew;
+}
+
+// ------------------------------------------------------------- flush + CRC
+
+// Write ring[flushed, upto) to global memory (coalesced 16-byte stores) and fold
+// it into the running CRC register.  `flushed` is a multiple of 16; `upto` too
+// unless this is the last flush.  Uses the stage area for the CRC tables.
+OTZ_DEV void otz_flush(otz_inflate_lds &L, const otz_job &J, u32 &flushed, u32 upto, u32 &crc_reg) {
+	u32 n = upto - flushed;
+	if (n == 0) {
+		return;
+	}
+	otz_sync ();
+	otz_crc_load_slice4 (L.crc_t4);
+	u32 nch = n >> 4, tail = n & 15u;
+	u32 tid = otz_tid ();
+	for (u32 c = tid; c < nch; c += OTZ_NT) {
+		u32 a = (flushed + 16u * c) & OTZ_RING_MASK;
+		otz_u4 v = *reinterpret_cast<const otz_u4 *> (&L.ring[a]);
+		otz_st16_aligned (J.out + flushed + 16u * c, v);
+	}
+	if (tid < tail) {
+		J.out[flushed + 16u * nch + tid] = L.ring[(flushed + 16u * nch + tid) & OTZ_RING_MASK];
+	}
+	otz_sync ();
+	// contiguous run of chunks per lane; an odd run length keeps the 16-byte LDS
+	// reads of a wave on distinct bank quads
+	u32 cpt = ((nch + OTZ_NT - 1u) / OTZ_NT) | 1u;
+	u32 c0 = tid * cpt, c1 = c0 + cpt;
+	if (c1 > nch) {
+		c1 = nch;
+	}
+	u32 r = 0;
+	for (u32 c = c0; c < c1; c++) {
+		u32 a = (flushed + 16u * c) & OTZ_RING_MASK;
+		otz_u4 v = *reinterpret_cast<const otz_u4 *> (&L.ring[a]);
+		r = otz_crc_chunk16 (r, v, L.crc_t4);
+	}
+	if (c0 < c1) {
+		u32 after = n - 16u * c1;
+		if (after) {
+			r = otz_gf_mul (r, otz_xpow_bytes (after));
+		}
+	}
+	if (tail && tid == OTZ_NT - 1u) {
+		u32 rt = 0;
+		for (u32 k = 0; k < tail; k++) {
+			rt = otz_crc_byte (rt, L.ring[(flushed + 16u * nch + k) & OTZ_RING_MASK], L.crc_t4);
+		}
+		r ^= rt;
+	}
+	u32 R = otz_block_xor (r, L.scan);
+	crc_reg = otz_gf_mul (crc_reg, otz_xpow_bytes (n)) ^ R;
+	flushed = upto;
+	otz_sync ();
+}
+
+// Make room for `need` more bytes at opos: everything older than 64 KiB - need
+// must already be in global memory.
+OTZ_DEV void otz_make_room(otz_inflate_lds &L, const otz_job &J, u32 opos, u32 need, u32 &flushed, u32 &crc_reg) {
+	if (opos + need - flushed > OTZ_RING) {
+		otz_flush (L, J, flushed, opos & ~15u, crc_reg);
+	}
+}
+
+// -------------------------------------------------------------- table build
+
+// Histogram + canonical bookkeeping for n code lengths at ll[0..n). Returns
+// false when the set is over-subscribed.  Called by one work-item.
+OTZ_DEV bool otz_canon_build(otz_canon &c, const u32 *hist) {
+	u32 code = 0, off = 0;
+	int left = 1;
+	c.first[0] = 0;
+	c.count[0] = 0;
+	c.off[0] = 0;
+	u32 prev = 0;
+	for (u32 l = 1; l <= 15; l++) {
+		u32 cnt = hist[l];
+		code = (code + prev) << 1;
+		c.first[l] = (u16)code;
+		c.count[l] = (u16)cnt;
+		c.off[l] = (u16)off;
+		off += cnt;
+		prev = cnt;
+		left = (left << 1) - (int)cnt;
+		if (left < 0) {
+			return false;
+		}
+	}
+	return true;
+}
+
+// Rank symbols of each length in index order (one wavefront, ballot-based).
+OTZ_DEV void otz_sort_syms(const otz_canon &c, const u8 *ll, u32 n, u16 *sorted) {
+	u32 lane = otz_lane ();
+	u64 lt = (1ull << lane) - 1ull;
+	for (u32 l = 1; l <= 15; l++) {
+		if (c.count[l] == 0) {
+			continue;
+		}
+		u32 base = c.off[l];
+		for (u32 s0 = 0; s0 < n; s0 += 64) {
+			u32 sym = s0 + lane;
+			bool mine = sym < n && ll[sym] == l;
+			u64 m = otz_ballot (mine);
+			if (mine) {
+				sorted[base + otz_popc64 (m & lt)] = (u16)sym;
+			}
+			base += otz_popc64 (m);
+		}
+	}
+}
+
+// Build both decode tables from L.ll[0..hlit+hdist). All work-items; returns
+// false (uniformly) on an over-subscribed set.
+OTZ_DEV bool otz_build_tables(otz_inflate_lds &L, u32 hlit, u32 hdist) {
+	u32 tid = otz_tid ();
+	if (tid < 32u) {
+		L.hist[tid] = 0;
+	}
+	otz_sync ();
+	for (u32 i = tid; i < hlit + hdist; i += OTZ_NT) {
+		u32 l = L.ll[i];
+		if (l) {
+			otz_lds_add (&L.hist[(i < hlit ? 0u : 16u) + l], 1u);
+		}
+	}
+	otz_sync ();
+	if (tid == 0) {
+		bool ok = otz_canon_build (L.lit_c, &L.hist[0]);
+		L.flag = ok ? 1u : 0u;
+	}
+	if (tid == 64u) {
+		bool ok = otz_canon_build (L.dist_c, &L.hist[16]);
+		L.first_rej = ok ? 1u : 0u;
+	}
+	otz_sync ();
+	bool ok = L.flag != 0u && L.first_rej != 0u;
+	if (!ok) {
+		return false;
+	}
+	if (otz_wave () == 0) {
+		otz_sort_syms (L.lit_c, L.ll, hlit, L.lit_sorted);
+	} else if (otz_wave () == 1) {
+		otz_sort_syms (L.dist_c, L.ll + hlit, hdist, L.dist_sorted);
+	}
+	otz_sync ();
+	for (u32 i = tid; i < (1u << OTZ_LIT_ROOT); i += OTZ_NT) {
+		u32 l;
+		u32 k = otz_canon_lookup (L.lit_c, i, 1, OTZ_LIT_ROOT, &l);
+		L.lit_lut[i] = l ? otz_mk_lit_entry (L.lit_sorted[k], l) : 0u;
+	}
+	for (u32 i = tid; i < (1u << OTZ_DIST_ROOT); i += OTZ_NT) {
+		u32 l;
+		u32 k = otz_canon_lookup (L.dist_c, i, 1, OTZ_DIST_ROOT, &l);
+		L.dist_lut[i] = l ? otz_mk_dist_entry (L.dist_sorted[k], l) : 0u;
+	}
+	otz_sync ();
+	return true;
+}
+
+// ------------------------------------------------------------ block headers
+
+// Work-item 0: parse BFINAL/BTYPE and, for a dynamic block, HLIT/HDIST/HCLEN and
+// the code-length code lengths (ref deflate-dec.inc.c:613-627, :122-156).
+// p = stage-relative bit position, avail = input bits left from p.
+OTZ_DEV void otz_parse_header_a(otz_inflate_lds &L, u32 p, u64 avail) {
+	otz_br r;
+	otz_br_init (r, L.stage_w, p);
+	otz_br_refill (r, L.stage_w);
+	if (avail < 3) {
+		otz_set_status (L, OZG_ST_BUF);
+		return;
+	}
+	L.bfinal = (u32)r.bb & 1u;
+	L.btype = ((u32)r.bb >> 1) & 3u;
+	otz_br_drop (r, 3);
+	u32 used = 3;
+	if (L.btype == 3u) {
+		otz_set_status (L, OZG_ST_DATA);
+		return;
+	}
+	if (L.btype == 2u) {
+		otz_br_refill (r, L.stage_w);
+		if (avail < used + 14u) {
+			otz_set_status (L, OZG_ST_DATA);
+			return;
+		}
+		u32 hlit = ((u32)r.bb & 31u) + 257u;
+		u32 hdist = (((u32)r.bb >> 5) & 31u) + 1u;
+		u32 hclen = (((u32)r.bb >> 10) & 15u) + 4u;
+		otz_br_drop (r, 14);
+		used += 14;
+		if (avail < used + 3u * hclen) {
+			otz_set_status (L, OZG_ST_DATA);
+			return;
+		}
+		const u8 order[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
+		for (u32 i = 0; i < 19; i++) {
+			L.cl_len[i] = 0;
+		}
+		for (u32 i = 0; i < hclen; i++) {
+			otz_br_refill (r, L.stage_w);
+			L.cl_len[order[i]] = (u8) ((u32)r.bb & 7u);
+			otz_br_drop (r, 3);
+		}
+		used += 3u * hclen;
+		L.hlit = hlit;
+		L.hdist = hdist;
+		// reference limit: LL_LENGTHS_MAX = 318 (:165-168); beyond it the
+		// reference reads outside ll_lengths[] -- fail cleanly instead
+		if (hlit + hdist > 318u) {
+			otz_set_status (L, OZG_ST_DATA);
+			return;
+		}
+		// code-length code: canonical bookkeeping
+		u32 hist[16];
+		for (u32 l = 0; l < 16; l++) {
+			hist[l] = 0;
+		}
+		for (u32 i = 0; i < 19; i++) {
+			hist[L.cl_len[i]]++;
+		}
+		hist[0] = 0;
+		if (!otz_canon_build (L.cl_c, hist)) {
+			otz_set_status (L, OZG_ST_DATA);
+			return;
+		}
+		u32 nxt[8];
+		for (u32 l = 0; l < 8; l++) {
+			nxt[l] = L.cl_c.off[l];
+		}
+		for (u32 i = 0; i < 19; i++) {
+			u32 l = L.cl_len[i];
+			if (l) {
+				L.cl_sorted[nxt[l]++] = (u8)i;
+			}
+		}
+	}
+	L.hdr_bits = used;
+}
+
+// Work-item 0: decode hlit+hdist code lengths with the 7-bit LUT
+// (ref deflate-dec.inc.c:164-253).
+OTZ_DEV void otz_parse_header_b(otz_inflate_lds &L, u32 p, u64 avail) {
+	otz_br r;
+	otz_br_init (r, L.stage_w, p);
+	u32 used = 0, n = L.hlit + L.hdist, idx = 0;
+	while (idx < n) {
+		otz_br_refill (r, L.stage_w);
+		u32 e = L.cl_lut[(u32)r.bb & 127u];
+		u32 l = e & 15u;
+		if (l == 0) {
+			otz_set_status (L, OZG_ST_DATA);
+			return;
+		}
+		u32 sym = e >> 8;
+		otz_br_drop (r, l);
+		used += l;
+		if (sym < 16u) {
+			L.ll[idx++] = (u8)sym;
+		} else {
+			u32 xb = sym == 16u ? 2u : sym == 17u ? 3u : 7u;
+			u32 rep = ((u32)r.bb & ((1u << xb) - 1u)) + (sym == 18u ? 11u : 3u);
+			otz_br_drop (r, xb);
+			used += xb;
+			u8 v = 0;
+			if (sym == 16u) {
+				if (idx == 0) {
+					otz_set_status (L, OZG_ST_DATA);
+					return;
+				}
+				v = L.ll[idx - 1];
+			}
+			if (idx + rep > n) {
+				otz_set_status (L, OZG_ST_DATA);
+				return;
+			}
+			for (u32 k = 0; k < rep; k++) {
+				L.ll[idx++] = v;
+			}
+		}
+		if ((u64)used > avail) {
+			otz_set_status (L, OZG_ST_DATA);
+			return;
+		}
+	}
+	L.hdr_bits = used;
+}
+
+// ------------------------------------------------------------------- passes
+
+struct otz_path {
+	u32 exit;  // exit word
+	u32 bytes; // output bytes of the tokens walked
+	u32 syncq; // MODE_B: position where the walk met pass A's path, or ~0u
+};
+
+#define OTZ_MODE_A 0      // from the speculative start; records visited token starts
+#define OTZ_MODE_B 1      // from the true start; stops on a visited position
+#define OTZ_MODE_PREFIX 2 // from the speculative start up to `stop`
+
+template <int MODE>
+OTZ_DEV otz_path otz_walk(const otz_inflate_lds &L, u32 start, u32 s, u32 e, u32 limit_bits, u32 stop, u32 (&vis)[4]) {
+	otz_path P;
+	P.bytes = 0;
+	P.syncq = ~0u;
+	otz_br r;
+	otz_br_init (r, L.stage_w, start);
+	u32 pos = start, ntok = 0;
+	for (;;) {
+		if (MODE == OTZ_MODE_PREFIX) {
+			if (pos >= stop) {
+				P.exit = OTZ_X_MAKE (OTZ_X_NORMAL, pos);
+				return P;
+			}
+		} else {
+			if (pos >= e) {
+				P.exit = OTZ_X_MAKE (OTZ_X_NORMAL, pos);
+				return P;
+			}
+		}
+		u32 rel = pos - s; // pos >= s always (a left neighbour exits at or after s)
+		if (MODE == OTZ_MODE_A) {
+			if (ntok >= OTZ_TOK_CAP) {
+				P.exit = OTZ_X_MAKE (OTZ_X_CUT, pos);
+				return P;
+			}
+			u32 bit = 1u << (rel & 31u), k = rel >> 5;
+			vis[0] |= k == 0 ? bit : 0u;
+			vis[1] |= k == 1 ? bit : 0u;
+			vis[2] |= k == 2 ? bit : 0u;
+			vis[3] |= k == 3 ? bit : 0u;
+		}
+		if (MODE == OTZ_MODE_B) {
+			u32 k = rel >> 5;
+			u32 w = k == 0 ? vis[0] : k == 1 ? vis[1] : k == 2 ? vis[2] : vis[3];
+			if ((w >> (rel & 31u)) & 1u) {
+				P.syncq = pos;
+				return P;
+			}
+		}
+		if (pos >= limit_bits) {
+			P.exit = OTZ_X_MAKE (OTZ_X_TRUNC, pos);
+			return P;
+		}
+		otz_tok t = otz_decode_token (L, r);
+		if (t.kind == OTZ_K_BAD) {
+			P.exit = OTZ_X_MAKE (OTZ_X_INVALID, pos);
+			return P;
+		}
+		if (pos + t.nbits > limit_bits) {
+			P.exit = OTZ_X_MAKE (OTZ_X_TRUNC, pos);
+			return P;
+		}
+		pos += t.nbits;
+		ntok++;
+		if (t.kind == OTZ_K_EOB) {
+			P.exit = OTZ_X_MAKE (OTZ_X_EOB, pos);
+			return P;
+		}
+		P.bytes += t.kind == OTZ_K_LIT ? 1u : t.val;
+	}
+}
+
+OTZ_DEV void otz_mark_final(otz_inflate_lds &L, u32 a, u32 b) {
+	// bits [a, b) of the round-relative final bitmap
+	if (a >= b) {
+		return;
+	}
+	otz_fence_release ();
+	u32 w0 = a >> 5, w1 = (b - 1u) >> 5;
+	for (u32 w = w0; w <= w1; w++) {
+		u32 lo = w == w0 ? (a & 31u) : 0u;
+		u32 hi = w == w1 ? ((b - 1u) & 31u) : 31u;
+		u32 m = (0xFFFFFFFFu >> (31u - hi)) & (0xFFFFFFFFu << lo);
+		otz_lds_or (&L.fin[w], m);
+	}
+}
+
+OTZ_DEV bool otz_all_final(const otz_inflate_lds &L, u32 a, u32 b) {
+	if (a >= b) {
+		return true;
+	}
+	u32 w0 = a >> 5, w1 = (b - 1u) >> 5;
+	for (u32 w = w0; w <= w1; w++) {
+		u32 lo = w == w0 ? (a & 31u) : 0u;
+		u32 hi = w == w1 ? ((b - 1u) & 31u) : 31u;
+		u32 m = (0xFFFFFFFFu >> (31u - hi)) & (0xFFFFFFFFu << lo);
+		if ((otz_lds_load (&L.fin[w]) & m) != m) {
+			return false;
+		}
+	}
+	otz_fence_acquire ();
+	return true;
+}
+
+// Pass C for one lane: decode the lane's tokens again from its true start and
+// materialise them.  One flat loop: a lane that must wait for another lane's
+// bytes never blocks the lanes it is waiting for.
+OTZ_DEV void otz_emit(otz_inflate_lds &L, bool active, u32 start, u32 exit_word, u32 o, u32 round_base, u64 stage_abs_bit) {
+	if (!active) {
+		return;
+	}
+	u32 exit_pos = OTZ_X_POS (exit_word);
+	otz_br r;
+	otz_br_init (r, L.stage_w, start);
+	u32 pos = start, run_start = o, pend = 0, pdist = 0, spins = 0;
+	bool ready = false;
+	for (;;) {
+		if (pend == 0) {
+			if (pos >= exit_pos) {
+				otz_mark_final (L, run_start - round_base, o - round_base);
+				return;
+			}
+			otz_tok t = otz_decode_token (L, r);
+			u32 tpos = pos;
+			pos += t.nbits;
+			if (t.kind == OTZ_K_LIT) {
+				L.ring[o & OTZ_RING_MASK] = (u8)t.val;
+				o++;
+				continue;
+			}
+			otz_mark_final (L, run_start - round_base, o - round_base);
+			run_start = o;
+			if (t.kind == OTZ_K_EOB) {
+				u64 a = stage_abs_bit + tpos;
+				L.eob_start_lo = (u32)a;
+				L.eob_start_hi = (u32) (a >> 32);
+				return;
+			}
+			if (t.kind != OTZ_K_LEN) {
+				otz_set_status (L, OZG_ST_INTERNAL); // validated path cannot hold a bad token
+				return;
+			}
+			if (t.dist > o) {
+				// ref reads window bytes nobody wrote (:524): no parity, fail cleanly
+				otz_set_status (L, OZG_ST_DATA);
+				return;
+			}
+			pend = t.val;
+			pdist = t.dist;
+			ready = false;
+		}
+		if (!ready) {
+			u32 s0 = o - pdist;
+			u32 e0 = s0 + (pend < pdist ? pend : pdist);
+			if (e0 <= round_base) {
+				ready = true;
+			} else {
+				u32 a = s0 > round_base ? s0 - round_base : 0u;
+				ready = otz_all_final (L, a, e0 - round_base);
+			}
+			if (!ready) {
+				if (otz_get_status (L) != 0 || ++spins > OTZ_SPIN_LIMIT) {
+					if (otz_get_status (L) == 0) {
+						otz_set_status (L, OZG_ST_INTERNAL);
+					}
+					return;
+				}
+				otz_backoff ();
+				continue;
+			}
+		}
+		u32 n = pend < 8u ? pend : 8u;
+		if (pdist >= n) {
+			u8 tmp[8];
+#pragma unroll
+			for (u32 k = 0; k < 8; k++) {
+				if (k < n) {
+					tmp[k] = L.ring[(o - pdist + k) & OTZ_RING_MASK];
+				}
+			}
+#pragma unroll
+			for (u32 k = 0; k < 8; k++) {
+				if (k < n) {
+					L.ring[(o + k) & OTZ_RING_MASK] = tmp[k];
+				}
+			}
+		} else {
+			for (u32 k = 0; k < n; k++) {
+				L.ring[(o + k) & OTZ_RING_MASK] = L.ring[(o + k - pdist) & OTZ_RING_MASK];
+			}
+		}
+		otz_mark_final (L, o - round_base, o + n - round_base);
+		o += n;
+		pend -= n;
+		run_start = o;
+	}
+}
+
+// Cooperative copy of n input bytes (entry offset src_byte) to the ring at opos.
+OTZ_DEV void otz_copy_in(otz_inflate_lds &L, const otz_job &J, u32 src_byte, u32 opos, u32 n) {
+	for (u32 i = otz_tid (); i < n; i += OTZ_NT) {
+		L.ring[(opos + i) & OTZ_RING_MASK] = J.in[src_byte + i];
+	}
+}
+OTZ_DEV void otz_fill_zero(otz_inflate_lds &L, u32 opos, u32 n) {
+	for (u32 i = otz_tid (); i < n; i += OTZ_NT) {
+		L.ring[(opos + i) & OTZ_RING_MASK] = 0;
+	}
+}
+
+// ----------------------------------------------------------------- the entry
+
+// Every work-item calls this with the same st: the barriers keep the write to
+// L.status away from work-items that are still reading it.
+OTZ_DEV void otz_fail_all(otz_inflate_lds &L, int st) {
+	otz_sync ();
+	if (otz_tid () == 0) {
+		otz_set_status (L, st);
+	}
+	otz_sync ();
+}
+
+// Decode one entry. All OTZ_NT work-items of the workgroup call this together.
+// Work-item 0 writes *res.
+OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_crc, ozg_result *res) {
+	const u32 tid = otz_tid ();
+	u64 abs_bit = 0;               // next input bit
+	const u64 total_bits = (u64)J.n_in * 8u;
+	u32 opos = 0, flushed = 0;     // bytes produced / already in global memory
+	u32 crc_reg = 0xFFFFFFFFu;
+	u32 flags = 0;
+	bool last_block = false, ended = false;
+
+	{
+		// uniform start-up verdict; nobody reads L.status before the barrier
+		int st0 = 0;
+		if (((uintptr_t)J.out & 15u) != 0) {
+			st0 = OZG_ST_INTERNAL;
+		} else if (J.n_in == 0) {
+			// ref: the loop at :610 never runs; Z_OK when there is no output space, else Z_BUF_ERROR
+			st0 = J.out_cap == 0 ? OTZ_ST_NEED_OUT_INT : OZG_ST_BUF;
+		}
+		if (tid == 0) {
+			otz_set_status (L, st0);
+			L.eob_start_lo = L.eob_start_hi = 0;
+			L.btype = 0;
+		}
+		otz_sync ();
+	}
+
+	while (otz_get_status (L) == 0 && !ended) {
+		// ---- block header
+		u32 byte0 = (u32) (abs_bit >> 3);
+		otz_sync ();
+		u32 skew = otz_stage_load (L, J, byte0);
+		otz_sync ();
+		u32 p0 = skew * 8u + (u32) (abs_bit & 7u);
+		u64 stage_abs = abs_bit - p0; // absolute bit position of stage bit 0 (may wrap below zero; only sums are used)
+		if (tid == 0) {
+			otz_parse_header_a (L, p0, total_bits - abs_bit);
+		}
+		otz_sync ();
+		if (otz_get_status (L) != 0) {
+			break;
+		}
+		last_block = L.bfinal != 0;
+		u32 btype = L.btype;
+		abs_bit += L.hdr_bits;
+		if (btype == 0) {
+			// ---- stored block (ref read_uncompressed_block :269-319)
+			abs_bit = (abs_bit + 7u) & ~(u64)7u;
+			u32 b = (u32) (abs_bit >> 3);
+			if (J.n_in - b < 4u || b > J.n_in) {
+				otz_fail_all (L, OZG_ST_DATA);
+				break;
+			}
+			u32 len = (u32)J.in[b] | ((u32)J.in[b + 1] << 8);
+			u32 nlen = (u32)J.in[b + 2] | ((u32)J.in[b + 3] << 8);
+			b += 4;
+			int st = 0;
+			if (len != ((~nlen) & 0xFFFFu)) {
+				st = OZG_ST_DATA;
+			} else if (J.n_in - b < len) {
+				st = OZG_ST_DATA;
+			} else if (J.out_cap - opos < len) {
+				st = OZG_ST_BUF; // ref :299-301
+			}
+			if (st != 0) {
+				otz_fail_all (L, st);
+				break;
+			}
+			u32 done = 0;
+			while (done < len) {
+				u32 n = len - done;
+				if (n > OTZ_RMAX) {
+					n = OTZ_RMAX;
+				}
+				otz_make_room (L, J, opos, n, flushed, crc_reg);
+				otz_copy_in (L, J, b + done, opos, n);
+				opos += n;
+				done += n;
+				otz_sync ();
+			}
+			abs_bit = ((u64)b + len) * 8u;
+			if (last_block) {
+				ended = true;
+			}
+			continue;
+		}
+		// ---- Huffman block: code lengths
+		if (btype == 1) {
+			for (u32 i = tid; i < 320u; i += OTZ_NT) {
+				L.ll[i] = (u8) (i <= 143u ? 8 : i <= 255u ? 9 : i <= 279u ? 7 : i <= 287u ? 8 : 5);
+			}
+			if (tid == 0) {
+				L.hlit = 288;
+				L.hdist = 32;
+			}
+			otz_sync ();
+		} else {
+			// 7-bit LUT of the code-length code, then the run-length coded lengths
+			if (tid < 128u) {
+				u32 l;
+				u32 k = otz_canon_lookup (L.cl_c, tid, 1, 7, &l);
+				L.cl_lut[tid] = l ? (((u32)L.cl_sorted[k] << 8) | l) : 0u;
+			}
+			otz_sync ();
+			if (tid == 0) {
+				otz_parse_header_b (L, p0 + L.hdr_bits, total_bits - abs_bit);
+			}
+			otz_sync ();
+			if (otz_get_status (L) != 0) {
+				break;
+			}
+			abs_bit += L.hdr_bits;
+		}
+		{
+			u32 hlit = L.hlit, hdist = L.hdist;
+			if (!otz_build_tables (L, hlit, hdist)) {
+				otz_fail_all (L, OZG_ST_DATA);
+				break;
+			}
+		}
+
+		// ---- rounds over the block's symbols
+		bool block_done = false;
+		while (!block_done) {
+			u32 room = J.out_cap - opos;
+			u32 limit = room < OTZ_RMAX ? room : OTZ_RMAX;
+			otz_make_room (L, J, opos, limit, flushed, crc_reg);
+			byte0 = (u32) (abs_bit >> 3);
+			otz_sync ();
+			skew = otz_stage_load (L, J, byte0);
+			p0 = skew * 8u + (u32) (abs_bit & 7u);
+			stage_abs = abs_bit - p0;
+			u64 lb = total_bits - stage_abs; // input ends at this stage-relative bit
+			u32 limit_bits = lb > 0xFFFFFFu ? 0xFFFFFFu : (u32)lb;
+			if (tid == 0) {
+				L.flag = 0;
+				L.first_term = OTZ_NT;
+				L.first_rej = OTZ_NT;
+				L.next_start = 0;
+			}
+			otz_sync ();
+
+			// pass A
+			const u32 s = p0 + tid * OTZ_S_BITS, e = s + OTZ_S_BITS;
+			u32 vis[4] = { 0, 0, 0, 0 };
+			otz_path A = otz_walk<OTZ_MODE_A> (L, s, s, e, limit_bits, 0, vis);
+			L.exits[tid] = A.exit;
+			otz_sync ();
+
+			// pass B: fixpoint over true starts.  A lane whose left neighbour's path
+			// terminated (EOB, cut, bad code, end of input) has no true start and is
+			// ignored below: only lanes up to the FIRST terminator are on the chain.
+			u32 t = tid == 0 ? s : ~0u;
+			u32 q = tid == 0 ? s : ~0u; // where the true path meets pass A's path (~0u: never)
+			u32 wbytes = 0;
+			u32 my_exit = A.exit;
+			for (u32 it = 0; it <= OTZ_NT; it++) {
+				u32 prev = tid ? L.exits[tid - 1] : 0u;
+				otz_sync ();
+				bool changed = false;
+				if (tid && OTZ_X_KIND (prev) == OTZ_X_NORMAL && OTZ_X_POS (prev) != t) {
+					t = OTZ_X_POS (prev);
+					otz_path B = otz_walk<OTZ_MODE_B> (L, t, s, e, limit_bits, 0, vis);
+					wbytes = B.bytes;
+					q = B.syncq;
+					u32 ne = q != ~0u ? A.exit : B.exit;
+					if (ne != my_exit) {
+						my_exit = ne;
+						L.exits[tid] = ne;
+						changed = true;
+					}
+				}
+				if (changed) {
+					otz_lds_store (&L.flag, it + 1u);
+				}
+				otz_sync ();
+				if (otz_lds_load (&L.flag) != it + 1u) {
+					break;
+				}
+			}
+			// output bytes of this lane's true path
+			u32 bytes = 0;
+			if (t != ~0u) {
+				if (q == ~0u) {
+					bytes = wbytes;
+				} else {
+					u32 pre = 0;
+					if (q != s) {
+						u32 dummy[4] = { 0, 0, 0, 0 };
+						pre = otz_walk<OTZ_MODE_PREFIX> (L, s, s, e, limit_bits, q, dummy).bytes;
+					}
+					bytes = wbytes + A.bytes - pre;
+				}
+			}
+			if (OTZ_X_KIND (my_exit) != OTZ_X_NORMAL) {
+				otz_lds_min (&L.first_term, tid);
+			}
+			u32 total;
+			u32 incl = otz_block_scan_incl (bytes, L.scan, &total);
+			const u32 F = L.first_term; // first lane whose path terminates; lanes <= F are the true chain
+			bool onchain = tid <= F;
+			bool acc = onchain && incl <= limit;
+			if (!acc) {
+				otz_lds_min (&L.first_rej, tid);
+			}
+			otz_sync ();
+			const u32 K = L.first_rej; // lanes [0, K) are materialised this round
+			if (tid == K && onchain) {
+				L.next_start = t; // true start of the first lane that did not fit
+				L.rej_bytes_incl = incl;
+			}
+			if (K > 0 && tid == K - 1u) {
+				L.acc_bytes = incl;
+			}
+			u32 term_exit = F < OTZ_NT ? L.exits[F] : 0u;
+			u32 last_exit = L.exits[OTZ_NT - 1u];
+			otz_sync (); // exits[] is about to be reused as the final bitmap
+			int st = 0;
+			u32 tk = OTZ_X_KIND (term_exit);
+			if (F < K && (tk == OTZ_X_INVALID || tk == OTZ_X_TRUNC)) {
+				st = OZG_ST_DATA; // ref: Z_DATA_ERROR from get_bit / no matching code
+			} else if (K <= F && K < OTZ_NT && L.rej_bytes_incl > room) {
+				st = OTZ_ST_NEED_OUT_INT; // stream wants more than uncomp_size bytes (ref pending copy/literal, Z_OK)
+			}
+			if (st != 0) {
+				otz_fail_all (L, st);
+				break;
+			}
+			u32 produced = K > 0 ? L.acc_bytes : 0u;
+			u32 next_rel;
+			if (K > 0 && K - 1u == F) {
+				next_rel = OTZ_X_POS (term_exit);
+				block_done = tk == OTZ_X_EOB;
+			} else if (K == OTZ_NT) {
+				next_rel = OTZ_X_POS (last_exit);
+			} else {
+				next_rel = L.next_start;
+			}
+			// pass C
+			for (u32 i = tid; i < OTZ_RMAX / 32; i += OTZ_NT) {
+				L.fin[i] = 0;
+			}
+			otz_sync ();
+			otz_emit (L, tid < K, tid == 0 ? s : t, my_exit, opos + incl - bytes, opos, stage_abs);
+			otz_sync ();
+			if (otz_get_status (L) != 0) {
+				break;
+			}
+			opos += produced;
+			abs_bit = stage_abs + next_rel;
+		}
+		if (otz_get_status (L) != 0) {
+			break;
+		}
+		if (last_block) {
+			ended = true;
+		}
+	}
+
+	int status = otz_get_status (L);
+	if (status == 0) {
+		// ---- reached the end of the final block
+		status = OZG_ST_OK;
+		if (L.btype != 0) {
+			// the reference returns Z_BUF_ERROR when every input byte had
+			// already been loaded before the step that decodes the final EOB
+			u64 eob = ((u64)L.eob_start_hi << 32) | L.eob_start_lo;
+			if (((eob + 7u) >> 3) >= (u64)J.n_in) {
+				flags |= OZG_F_REF_FALSE_REJECT;
+			}
+		}
+		u32 produced = opos;
+		if (opos < J.out_cap) {
+			// short stream, zero-filled tail
+			flags |= OZG_F_SHORT_STREAM;
+			while (opos < J.out_cap) {
+				u32 n = J.out_cap - opos;
+				if (n > OTZ_RMAX) {
+					n = OTZ_RMAX;
+				}
+				otz_make_room (L, J, opos, n, flushed, crc_reg);
+				otz_sync ();
+				otz_fill_zero (L, opos, n);
+				opos += n;
+				otz_sync ();
+			}
+		}
+		otz_flush (L, J, flushed, opos, crc_reg);
+		u32 crc = ~crc_reg;
+		if (crc != expect_crc) {
+			flags |= OZG_F_CRC_MISMATCH;
+		}
+		if (tid == 0) {
+			res->status = OZG_ST_OK;
+			res->total_out = produced;
+			res->crc32 = crc;
+			res->flags = flags;
+		}
+	} else if (tid == 0) {
+		res->status = status == OTZ_ST_NEED_OUT_INT ? OZG_ST_NEED_OUT : status;
+		res->total_out = opos;
+		res->crc32 = 0;
+		res->flags = 0;
+	}
+}

@@ -1,0 +1,78 @@
+// otz_simt.h -- the handful of SIMT primitives the codec kernels are written against.
+//
+// Product build (hipcc, gfx950): everything below maps 1:1 onto CDNA4 wave64 /
+// LDS / workgroup-barrier instructions.  There is no CPU code path in the
+// shipped library.
+//
+// tests/simt_emu/ provides a second definition of the same names on top of
+// pthreads so that the *same kernel bodies* can be run under g++/ASan on a
+// machine without a GPU (GPU AddressSanitizer is not available on the pool).
+// That emulation is test infrastructure; it is only reachable when a test
+// build passes -DOTZ_SIMT_EMU and puts tests/simt_emu on the include path.
+#pragma once
+
+#include <stdint.h>
+
+#ifdef OTZ_SIMT_EMU
+#include "otz_simt_emu.h"
+#else
+
+#include <hip/hip_runtime.h>
+
+#define OTZ_DEV __device__ __forceinline__
+#define OTZ_DEV_NOINLINE __device__ __noinline__
+#define OTZ_CONST_TABLE __device__ const
+#define OTZ_WAVE 64
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef uint16_t u16;
+typedef uint8_t u8;
+
+struct otz_u4 {
+	u32 x, y, z, w;
+};
+
+OTZ_DEV u32 otz_tid() { return threadIdx.x; }
+OTZ_DEV u32 otz_lane() { return threadIdx.x & 63u; }
+OTZ_DEV u32 otz_wave() { return threadIdx.x >> 6; }
+OTZ_DEV u32 otz_nthreads() { return blockDim.x; }
+
+OTZ_DEV void otz_sync() { __syncthreads (); }
+
+// wave64 cross-lane
+OTZ_DEV u64 otz_ballot(bool p) { return __ballot (p); }
+OTZ_DEV u32 otz_shfl_up(u32 v, u32 d) { return (u32)__shfl_up ((int)v, d, 64); }
+OTZ_DEV u32 otz_shfl(u32 v, u32 src) { return (u32)__shfl ((int)v, (int)src, 64); }
+OTZ_DEV u32 otz_shfl_xor(u32 v, u32 m) { return (u32)__shfl_xor ((int)v, (int)m, 64); }
+
+// LDS atomics (workgroup scope)
+OTZ_DEV void otz_lds_or(u32 *p, u32 v) { __hip_atomic_fetch_or (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+OTZ_DEV void otz_lds_min(u32 *p, u32 v) { __hip_atomic_fetch_min (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+OTZ_DEV void otz_lds_max(u32 *p, u32 v) { __hip_atomic_fetch_max (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+OTZ_DEV u32 otz_lds_add(u32 *p, u32 v) { return __hip_atomic_fetch_add (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+OTZ_DEV u32 otz_lds_load(const u32 *p) { return __hip_atomic_load (p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+OTZ_DEV void otz_lds_store(u32 *p, u32 v) { __hip_atomic_store (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// LDS is one in-order pipeline per CU; these only stop the compiler (and the
+// issuing wave) from reordering around a hand-off inside the workgroup.
+OTZ_DEV void otz_fence_release() { __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup"); }
+OTZ_DEV void otz_fence_acquire() { __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup"); }
+OTZ_DEV void otz_backoff() { __builtin_amdgcn_s_sleep (2); }
+
+OTZ_DEV u32 otz_popc(u32 v) { return (u32)__popc (v); }
+OTZ_DEV u32 otz_popc64(u64 v) { return (u32)__popcll (v); }
+OTZ_DEV u32 otz_brev(u32 v) { return __brev (v); }
+OTZ_DEV u32 otz_ctz(u32 v) { return (u32)__builtin_ctz (v); }
+
+// 16-byte global accesses.  gfx950 runs with unaligned global access enabled,
+// so an under-aligned source still lowers to one global_load_dwordx4.
+OTZ_DEV otz_u4 otz_ld16(const void *p) {
+	otz_u4 v;
+	__builtin_memcpy (&v, p, 16);
+	return v;
+}
+OTZ_DEV otz_u4 otz_ld16_aligned(const void *p) { return *reinterpret_cast<const otz_u4 *> (p); }
+OTZ_DEV void otz_st16_aligned(void *p, otz_u4 v) { *reinterpret_cast<otz_u4 *> (p) = v; }
+
+#endif // OTZ_SIMT_EMU

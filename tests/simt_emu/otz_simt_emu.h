@@ -1,0 +1,115 @@
+// otz_simt_emu.h -- pthread emulation of the SIMT primitives in
+// otezip_amd/csrc/otz_simt.h.  TEST INFRASTRUCTURE ONLY: lets the kernel
+// bodies run under g++ (-fsanitize=address,undefined) where no GPU exists.
+// One OS thread per work-item, one pthread barrier per workgroup and per wave.
+// Never compiled into the product library.
+#pragma once
+
+#include <pthread.h>
+#include <sched.h>
+#include <stdint.h>
+#include <string.h>
+
+#define OTZ_DEV static inline
+#define OTZ_DEV_NOINLINE static
+#define OTZ_CONST_TABLE static const
+#define OTZ_WAVE 64
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef uint16_t u16;
+typedef uint8_t u8;
+
+struct otz_u4 {
+	u32 x, y, z, w;
+};
+
+struct otz_emu_block {
+	u32 nthreads;
+	pthread_barrier_t block_bar;
+	pthread_barrier_t wave_bar[16];
+	u32 xchg[1024];
+};
+
+struct otz_emu_thread {
+	u32 tid;
+	otz_emu_block *blk;
+};
+
+extern thread_local otz_emu_thread otz_emu_self;
+
+OTZ_DEV u32 otz_tid() { return otz_emu_self.tid; }
+OTZ_DEV u32 otz_lane() { return otz_emu_self.tid & 63u; }
+OTZ_DEV u32 otz_wave() { return otz_emu_self.tid >> 6; }
+OTZ_DEV u32 otz_nthreads() { return otz_emu_self.blk->nthreads; }
+
+OTZ_DEV void otz_sync() { pthread_barrier_wait (&otz_emu_self.blk->block_bar); }
+OTZ_DEV void otz_emu_wave_sync() { pthread_barrier_wait (&otz_emu_self.blk->wave_bar[otz_wave ()]); }
+
+OTZ_DEV u64 otz_ballot(bool p) {
+	otz_emu_block *b = otz_emu_self.blk;
+	u32 base = otz_wave () * 64;
+	__atomic_store_n (&b->xchg[otz_tid ()], p ? 1u : 0u, __ATOMIC_RELAXED);
+	otz_emu_wave_sync ();
+	u64 m = 0;
+	for (u32 i = 0; i < 64 && base + i < b->nthreads; i++) {
+		if (__atomic_load_n (&b->xchg[base + i], __ATOMIC_RELAXED)) {
+			m |= 1ull << i;
+		}
+	}
+	otz_emu_wave_sync ();
+	return m;
+}
+
+OTZ_DEV u32 otz_shfl(u32 v, u32 src) {
+	otz_emu_block *b = otz_emu_self.blk;
+	u32 base = otz_wave () * 64;
+	__atomic_store_n (&b->xchg[otz_tid ()], v, __ATOMIC_RELAXED);
+	otz_emu_wave_sync ();
+	u32 r = __atomic_load_n (&b->xchg[base + (src & 63u)], __ATOMIC_RELAXED);
+	otz_emu_wave_sync ();
+	return r;
+}
+OTZ_DEV u32 otz_shfl_up(u32 v, u32 d) {
+	u32 l = otz_lane ();
+	u32 r = otz_shfl (v, l >= d ? l - d : l);
+	return r;
+}
+OTZ_DEV u32 otz_shfl_xor(u32 v, u32 m) { return otz_shfl (v, otz_lane () ^ m); }
+
+OTZ_DEV void otz_lds_or(u32 *p, u32 v) { __atomic_fetch_or (p, v, __ATOMIC_RELAXED); }
+OTZ_DEV void otz_lds_min(u32 *p, u32 v) {
+	u32 cur = __atomic_load_n (p, __ATOMIC_RELAXED);
+	while (v < cur && !__atomic_compare_exchange_n (p, &cur, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+	}
+}
+OTZ_DEV void otz_lds_max(u32 *p, u32 v) {
+	u32 cur = __atomic_load_n (p, __ATOMIC_RELAXED);
+	while (v > cur && !__atomic_compare_exchange_n (p, &cur, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+	}
+}
+OTZ_DEV u32 otz_lds_add(u32 *p, u32 v) { return __atomic_fetch_add (p, v, __ATOMIC_RELAXED); }
+OTZ_DEV u32 otz_lds_load(const u32 *p) { return __atomic_load_n (p, __ATOMIC_RELAXED); }
+OTZ_DEV void otz_lds_store(u32 *p, u32 v) { __atomic_store_n (p, v, __ATOMIC_RELAXED); }
+
+OTZ_DEV void otz_fence_release() { __atomic_thread_fence (__ATOMIC_RELEASE); }
+OTZ_DEV void otz_fence_acquire() { __atomic_thread_fence (__ATOMIC_ACQUIRE); }
+OTZ_DEV void otz_backoff() { sched_yield (); }
+
+OTZ_DEV u32 otz_popc(u32 v) { return (u32)__builtin_popcount (v); }
+OTZ_DEV u32 otz_popc64(u64 v) { return (u32)__builtin_popcountll (v); }
+OTZ_DEV u32 otz_brev(u32 v) {
+	v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+	v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+	v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+	return __builtin_bswap32 (v);
+}
+OTZ_DEV u32 otz_ctz(u32 v) { return (u32)__builtin_ctz (v); }
+
+OTZ_DEV otz_u4 otz_ld16(const void *p) {
+	otz_u4 v;
+	memcpy (&v, p, 16);
+	return v;
+}
+OTZ_DEV otz_u4 otz_ld16_aligned(const void *p) { return otz_ld16 (p); }
+OTZ_DEV void otz_st16_aligned(void *p, otz_u4 v) { memcpy (p, &v, 16); }
