@@ -64,6 +64,7 @@ ABI = {
     "ozg_memcpy_h2d": (C.c_int, [_VP, _VP, C.c_size_t, _VP]),
     "ozg_memcpy_d2h": (C.c_int, [_VP, _VP, C.c_size_t, _VP]),
     "ozg_stream_sync": (C.c_int, [_VP]),
+    "ozg_debug_set_profile_buffer": (None, [_VP]),
     "ozg_kernel_name_inflate": (C.c_char_p, []),
     "ozg_kernel_name_copy": (C.c_char_p, []),
 }

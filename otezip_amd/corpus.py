@@ -66,6 +66,8 @@ def gen_text(seed, size):
         chunk = tab[toks[tok_of_byte], j]
         parts.append(chunk[:need])
         need -= min(need, total)
+    if not parts:
+        return b""
     out = np.concatenate(parts) if len(parts) > 1 else parts[0]
     return out.tobytes()
 

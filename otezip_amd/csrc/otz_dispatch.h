@@ -26,7 +26,7 @@ OTZ_DEV void otz_fail(ozg_result *r, int status) {
 }
 
 // DEFLATE entries (method 8). Entries of other methods are left to the copy kernel.
-OTZ_DEV void otz_run_inflate(otz_inflate_lds &L, const u8 *src, u8 *dst, const ozg_entry &e, ozg_result *r, const ozg_limits &lim) {
+OTZ_DEV void otz_run_inflate(otz_inflate_lds &L, const u8 *src, u8 *dst, const ozg_entry &e, ozg_result *r, const ozg_limits &lim, u64 *prof) {
 	if (e.method != OZG_METHOD_DEFLATE) {
 		return;
 	}
@@ -39,6 +39,7 @@ OTZ_DEV void otz_run_inflate(otz_inflate_lds &L, const u8 *src, u8 *dst, const o
 	J.n_in = e.comp_size;
 	J.out = dst + e.dst_off;
 	J.out_cap = e.uncomp_size;
+	J.prof = prof;
 	otz_inflate_entry (L, J, e.crc32, r);
 }
 

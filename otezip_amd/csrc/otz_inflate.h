@@ -44,7 +44,7 @@
 #define OTZ_STAGE_WORDS (OTZ_STAGE_BYTES / 4)
 #define OTZ_LIT_ROOT 10
 #define OTZ_DIST_ROOT 8
-#define OTZ_SPIN_LIMIT 4000000u
+#define OTZ_SPIN_LIMIT 1000000u
 #define OTZ_ST_NEED_OUT_INT (-100) // OZG_ST_NEED_OUT is 0, which L.status uses for "still decoding"
 
 // exit word of a lane's path: [23:0] stage-relative bit position, [26:24] kind
@@ -106,6 +106,10 @@ struct otz_inflate_lds {
 	u32 eob_start_lo, eob_start_hi;
 	u32 rej_bytes_incl;
 	u32 acc_bytes;
+	u32 dbg[4];      // failure diagnostics: reason, lane, position, aux
+	u32 bmin[2][2];  // pass B: per-iteration {first lane that changed, first terminated lane}
+	u64 prof_last;
+	u64 prof[16];    // diagnostic cycle counters per phase (only with a profile buffer)
 };
 
 struct otz_job {
@@ -113,9 +117,47 @@ struct otz_job {
 	u32 n_in;
 	u8 *out;
 	u32 out_cap;
+	u64 *prof; // optional: 16 x u64 phase cycle counters for this entry (diagnostics), or null
 };
 
+// phase ids of the diagnostic counters
+#define OTZ_P_HEADER 0
+#define OTZ_P_LENGTHS 1
+#define OTZ_P_TABLES 2
+#define OTZ_P_STAGE 3
+#define OTZ_P_PASS_A 4
+#define OTZ_P_PASS_B 5
+#define OTZ_P_SCAN 6
+#define OTZ_P_EMIT 7
+#define OTZ_P_FLUSH 8
+#define OTZ_P_STORED 9
+#define OTZ_P_ROUNDS 12
+#define OTZ_P_B_ITERS 13
+#define OTZ_P_BLOCKS 14
+#define OTZ_P_TOTAL 15
+
 // ------------------------------------------------------------------ helpers
+
+#ifdef OTZ_SIMT_EMU
+OTZ_DEV u64 otz_cycles() { return 0; }
+#else
+OTZ_DEV u64 otz_cycles() { return __builtin_readcyclecounter (); }
+#endif
+// work-item 0 charges the cycles since the previous mark to `phase`
+#define OTZ_MARK(L, J, phase) \
+	do { \
+		if ((J).prof && otz_tid () == 0) { \
+			u64 _t = otz_cycles (); \
+			(L).prof[phase] += _t - (L).prof_last; \
+			(L).prof_last = _t; \
+		} \
+	} while (0)
+#define OTZ_COUNT(L, J, phase, n) \
+	do { \
+		if ((J).prof && otz_tid () == 0) { \
+			(L).prof[phase] += (n); \
+		} \
+	} while (0)
 
 OTZ_DEV void otz_set_status(otz_inflate_lds &L, int st) { otz_lds_store (&L.status, (u32)st); }
 OTZ_DEV int otz_get_status(const otz_inflate_lds &L) { return (int)otz_lds_load (&L.status); }
@@ -325,6 +367,7 @@ OTZ_DEV void otz_flush(otz_inflate_lds &L, const otz_job &J, u32 &flushed, u32 u
 		return;
 	}
 	otz_sync ();
+	OTZ_MARK (L, J, OTZ_P_SCAN);
 	otz_crc_load_slice4 (L.crc_t4);
 	u32 nch = n >> 4, tail = n & 15u;
 	u32 tid = otz_tid ();
@@ -367,6 +410,7 @@ OTZ_DEV void otz_flush(otz_inflate_lds &L, const otz_job &J, u32 &flushed, u32 u
 	crc_reg = otz_gf_mul (crc_reg, otz_xpow_bytes (n)) ^ R;
 	flushed = upto;
 	otz_sync ();
+	OTZ_MARK (L, J, OTZ_P_FLUSH);
 }
 
 // Make room for `need` more bytes at opos: everything older than 64 KiB - need
@@ -709,97 +753,115 @@ OTZ_DEV bool otz_all_final(const otz_inflate_lds &L, u32 a, u32 b) {
 	return true;
 }
 
-// Pass C for one lane: decode the lane's tokens again from its true start and
-// materialise them.  One flat loop: a lane that must wait for another lane's
-// bytes never blocks the lanes it is waiting for.
+// Pass C: every lane decodes its tokens again from its true start and
+// materialises them.  All 64 lanes of a wavefront stay in ONE loop and take at
+// most one step per trip; the ballot at the bottom is a convergent operation, so
+// the compiler cannot peel the "wait for another lane's bytes" path into an inner
+// loop (which would park the very lanes being waited for: SIMT deadlock).
+// Call from wave-uniform control flow; lanes with active == false just vote.
 OTZ_DEV void otz_emit(otz_inflate_lds &L, bool active, u32 start, u32 exit_word, u32 o, u32 round_base, u64 stage_abs_bit) {
-	if (!active) {
-		return;
-	}
 	u32 exit_pos = OTZ_X_POS (exit_word);
 	otz_br r;
-	otz_br_init (r, L.stage_w, start);
+	otz_br_init (r, L.stage_w, active ? start : 0u);
 	u32 pos = start, run_start = o, pend = 0, pdist = 0, spins = 0;
-	bool ready = false;
+	bool ready = false, done = !active;
 	for (;;) {
-		if (pend == 0) {
+		bool progressed = false;
+		if (!done && pend == 0) {
+			progressed = true;
 			if (pos >= exit_pos) {
 				otz_mark_final (L, run_start - round_base, o - round_base);
-				return;
-			}
-			otz_tok t = otz_decode_token (L, r);
-			u32 tpos = pos;
-			pos += t.nbits;
-			if (t.kind == OTZ_K_LIT) {
-				L.ring[o & OTZ_RING_MASK] = (u8)t.val;
-				o++;
-				continue;
-			}
-			otz_mark_final (L, run_start - round_base, o - round_base);
-			run_start = o;
-			if (t.kind == OTZ_K_EOB) {
-				u64 a = stage_abs_bit + tpos;
-				L.eob_start_lo = (u32)a;
-				L.eob_start_hi = (u32) (a >> 32);
-				return;
-			}
-			if (t.kind != OTZ_K_LEN) {
-				otz_set_status (L, OZG_ST_INTERNAL); // validated path cannot hold a bad token
-				return;
-			}
-			if (t.dist > o) {
-				// ref reads window bytes nobody wrote (:524): no parity, fail cleanly
-				otz_set_status (L, OZG_ST_DATA);
-				return;
-			}
-			pend = t.val;
-			pdist = t.dist;
-			ready = false;
-		}
-		if (!ready) {
-			u32 s0 = o - pdist;
-			u32 e0 = s0 + (pend < pdist ? pend : pdist);
-			if (e0 <= round_base) {
-				ready = true;
+				done = true;
 			} else {
-				u32 a = s0 > round_base ? s0 - round_base : 0u;
-				ready = otz_all_final (L, a, e0 - round_base);
-			}
-			if (!ready) {
-				if (otz_get_status (L) != 0 || ++spins > OTZ_SPIN_LIMIT) {
-					if (otz_get_status (L) == 0) {
+				otz_tok t = otz_decode_token (L, r);
+				u32 tpos = pos;
+				pos += t.nbits;
+				if (t.kind == OTZ_K_LIT) {
+					L.ring[o & OTZ_RING_MASK] = (u8)t.val;
+					o++;
+				} else {
+					otz_mark_final (L, run_start - round_base, o - round_base);
+					run_start = o;
+					if (t.kind == OTZ_K_EOB) {
+						u64 a = stage_abs_bit + tpos;
+						L.eob_start_lo = (u32)a;
+						L.eob_start_hi = (u32) (a >> 32);
+						done = true;
+					} else if (t.kind != OTZ_K_LEN) {
+						L.dbg[0] = 2; // validated path cannot hold a bad token
+						L.dbg[1] = otz_tid ();
+						L.dbg[2] = tpos;
+						L.dbg[3] = t.kind | (t.nbits << 8);
 						otz_set_status (L, OZG_ST_INTERNAL);
+						done = true;
+					} else if (t.dist > o) {
+						// ref reads window bytes nobody wrote (:524): no parity, fail cleanly
+						otz_set_status (L, OZG_ST_DATA);
+						done = true;
+					} else {
+						pend = t.val;
+						pdist = t.dist;
+						ready = false;
 					}
-					return;
 				}
-				otz_backoff ();
-				continue;
 			}
 		}
-		u32 n = pend < 8u ? pend : 8u;
-		if (pdist >= n) {
-			u8 tmp[8];
-#pragma unroll
-			for (u32 k = 0; k < 8; k++) {
-				if (k < n) {
-					tmp[k] = L.ring[(o - pdist + k) & OTZ_RING_MASK];
+		if (!done && pend != 0) {
+			if (!ready) {
+				u32 s0 = o - pdist;
+				u32 e0 = s0 + (pend < pdist ? pend : pdist);
+				if (e0 <= round_base) {
+					ready = true;
+				} else {
+					u32 a = s0 > round_base ? s0 - round_base : 0u;
+					ready = otz_all_final (L, a, e0 - round_base);
 				}
 			}
+			if (ready) {
+				progressed = true;
+				u32 n = pend < 8u ? pend : 8u;
+				if (pdist >= n) {
+					u8 tmp[8];
 #pragma unroll
-			for (u32 k = 0; k < 8; k++) {
-				if (k < n) {
-					L.ring[(o + k) & OTZ_RING_MASK] = tmp[k];
+					for (u32 k = 0; k < 8; k++) {
+						if (k < n) {
+							tmp[k] = L.ring[(o - pdist + k) & OTZ_RING_MASK];
+						}
+					}
+#pragma unroll
+					for (u32 k = 0; k < 8; k++) {
+						if (k < n) {
+							L.ring[(o + k) & OTZ_RING_MASK] = tmp[k];
+						}
+					}
+				} else {
+					for (u32 k = 0; k < n; k++) {
+						L.ring[(o + k) & OTZ_RING_MASK] = L.ring[(o + k - pdist) & OTZ_RING_MASK];
+					}
 				}
-			}
-		} else {
-			for (u32 k = 0; k < n; k++) {
-				L.ring[(o + k) & OTZ_RING_MASK] = L.ring[(o + k - pdist) & OTZ_RING_MASK];
+				otz_mark_final (L, o - round_base, o + n - round_base);
+				o += n;
+				pend -= n;
+				run_start = o;
+			} else if (otz_get_status (L) != 0) {
+				done = true;
+			} else if (++spins > OTZ_SPIN_LIMIT) {
+				L.dbg[0] = 3; // waited too long for source bytes
+				L.dbg[1] = otz_tid ();
+				L.dbg[2] = o;
+				L.dbg[3] = pdist | (pend << 16);
+				otz_set_status (L, OZG_ST_INTERNAL);
+				done = true;
 			}
 		}
-		otz_mark_final (L, o - round_base, o + n - round_base);
-		o += n;
-		pend -= n;
-		run_start = o;
+		u64 alive = otz_ballot (!done);
+		u64 moved = otz_ballot (progressed);
+		if (alive == 0) {
+			break;
+		}
+		if (moved == 0) {
+			otz_backoff (); // every live lane of this wavefront waits on another wavefront
+		}
 	}
 }
 
@@ -849,6 +911,13 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 		}
 		if (tid == 0) {
 			otz_set_status (L, st0);
+			L.dbg[0] = st0 == OZG_ST_INTERNAL ? 1u : 0u;
+			L.dbg[1] = L.dbg[2] = L.dbg[3] = 0;
+			for (u32 i = 0; i < 16; i++) {
+				L.prof[i] = 0;
+			}
+			L.prof_last = otz_cycles ();
+			L.prof[OTZ_P_TOTAL] = 0 - L.prof_last;
 			L.eob_start_lo = L.eob_start_hi = 0;
 			L.btype = 0;
 		}
@@ -863,10 +932,13 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 		otz_sync ();
 		u32 p0 = skew * 8u + (u32) (abs_bit & 7u);
 		u64 stage_abs = abs_bit - p0; // absolute bit position of stage bit 0 (may wrap below zero; only sums are used)
+		OTZ_MARK (L, J, OTZ_P_STAGE);
 		if (tid == 0) {
 			otz_parse_header_a (L, p0, total_bits - abs_bit);
 		}
 		otz_sync ();
+		OTZ_MARK (L, J, OTZ_P_HEADER);
+		OTZ_COUNT (L, J, OTZ_P_BLOCKS, 1);
 		if (otz_get_status (L) != 0) {
 			break;
 		}
@@ -909,6 +981,7 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 				otz_sync ();
 			}
 			abs_bit = ((u64)b + len) * 8u;
+			OTZ_MARK (L, J, OTZ_P_STORED);
 			if (last_block) {
 				ended = true;
 			}
@@ -936,6 +1009,7 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 				otz_parse_header_b (L, p0 + L.hdr_bits, total_bits - abs_bit);
 			}
 			otz_sync ();
+			OTZ_MARK (L, J, OTZ_P_LENGTHS);
 			if (otz_get_status (L) != 0) {
 				break;
 			}
@@ -949,6 +1023,7 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 			}
 		}
 
+		OTZ_MARK (L, J, OTZ_P_TABLES);
 		// ---- rounds over the block's symbols
 		bool block_done = false;
 		while (!block_done) {
@@ -970,6 +1045,8 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 			}
 			otz_sync ();
 
+			OTZ_MARK (L, J, OTZ_P_STAGE);
+			OTZ_COUNT (L, J, OTZ_P_ROUNDS, 1);
 			// pass A
 			const u32 s = p0 + tid * OTZ_S_BITS, e = s + OTZ_S_BITS;
 			u32 vis[4] = { 0, 0, 0, 0 };
@@ -977,17 +1054,26 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 			L.exits[tid] = A.exit;
 			otz_sync ();
 
+			OTZ_MARK (L, J, OTZ_P_PASS_A);
 			// pass B: fixpoint over true starts.  A lane whose left neighbour's path
 			// terminated (EOB, cut, bad code, end of input) has no true start and is
-			// ignored below: only lanes up to the FIRST terminator are on the chain.
+			// ignored below: only lanes up to the FIRST terminator are on the chain, so
+			// the iteration stops as soon as nothing at or left of it changed (lanes
+			// beyond it decode the next block's header as symbols and need not settle).
 			u32 t = tid == 0 ? s : ~0u;
 			u32 q = tid == 0 ? s : ~0u; // where the true path meets pass A's path (~0u: never)
 			u32 wbytes = 0;
 			u32 my_exit = A.exit;
+			if (tid == 0) {
+				L.bmin[0][0] = L.bmin[0][1] = OTZ_NT;
+			}
 			for (u32 it = 0; it <= OTZ_NT; it++) {
+				u32 slot = it & 1u;
 				u32 prev = tid ? L.exits[tid - 1] : 0u;
 				otz_sync ();
-				bool changed = false;
+				if (tid == 0) {
+					L.bmin[slot ^ 1u][0] = L.bmin[slot ^ 1u][1] = OTZ_NT;
+				}
 				if (tid && OTZ_X_KIND (prev) == OTZ_X_NORMAL && OTZ_X_POS (prev) != t) {
 					t = OTZ_X_POS (prev);
 					otz_path B = otz_walk<OTZ_MODE_B> (L, t, s, e, limit_bits, 0, vis);
@@ -997,17 +1083,20 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 					if (ne != my_exit) {
 						my_exit = ne;
 						L.exits[tid] = ne;
-						changed = true;
+						otz_lds_min (&L.bmin[slot][0], tid);
 					}
 				}
-				if (changed) {
-					otz_lds_store (&L.flag, it + 1u);
+				if (OTZ_X_KIND (my_exit) != OTZ_X_NORMAL) {
+					otz_lds_min (&L.bmin[slot][1], tid);
 				}
 				otz_sync ();
-				if (otz_lds_load (&L.flag) != it + 1u) {
+				OTZ_COUNT (L, J, OTZ_P_B_ITERS, 1);
+				u32 first_changed = L.bmin[slot][0], first_term = L.bmin[slot][1];
+				if (first_changed == OTZ_NT || first_changed > first_term) {
 					break;
 				}
 			}
+			OTZ_MARK (L, J, OTZ_P_PASS_B);
 			// output bytes of this lane's true path
 			u32 bytes = 0;
 			if (t != ~0u) {
@@ -1066,6 +1155,7 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 			} else {
 				next_rel = L.next_start;
 			}
+			OTZ_MARK (L, J, OTZ_P_SCAN);
 			// pass C
 			for (u32 i = tid; i < OTZ_RMAX / 32; i += OTZ_NT) {
 				L.fin[i] = 0;
@@ -1073,6 +1163,7 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 			otz_sync ();
 			otz_emit (L, tid < K, tid == 0 ? s : t, my_exit, opos + incl - bytes, opos, stage_abs);
 			otz_sync ();
+			OTZ_MARK (L, J, OTZ_P_EMIT);
 			if (otz_get_status (L) != 0) {
 				break;
 			}
@@ -1088,6 +1179,9 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 	}
 
 	int status = otz_get_status (L);
+	if (J.prof && tid == 0) {
+		L.prof[OTZ_P_TOTAL] += otz_cycles ();
+	}
 	if (status == 0) {
 		// ---- reached the end of the final block
 		status = OZG_ST_OK;
@@ -1126,10 +1220,16 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 			res->crc32 = crc;
 			res->flags = flags;
 		}
+		if (J.prof && tid == 0) {
+			L.prof[OTZ_P_FLUSH] += otz_cycles () - L.prof_last;
+			for (u32 i = 0; i < 16; i++) {
+				J.prof[i] = L.prof[i];
+			}
+		}
 	} else if (tid == 0) {
 		res->status = status == OTZ_ST_NEED_OUT_INT ? OZG_ST_NEED_OUT : status;
-		res->total_out = opos;
-		res->crc32 = 0;
-		res->flags = 0;
+		res->total_out = status == OZG_ST_INTERNAL ? L.dbg[1] : opos;
+		res->crc32 = status == OZG_ST_INTERNAL ? L.dbg[2] : 0;
+		res->flags = status == OZG_ST_INTERNAL ? (L.dbg[0] << 28) | (L.dbg[3] & 0x0FFFFFFF) : 0;
 	}
 }

@@ -24,7 +24,7 @@ static_assert (sizeof (ozg_result) == 16, "ozg_result ABI");
 static_assert (sizeof (otz_inflate_lds) <= 80 * 1024, "two inflate workgroups per CU");
 
 extern "C" __global__ void __launch_bounds__ (256)
-otz_inflate_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *results, u32 n, ozg_limits lim) {
+otz_inflate_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *results, u32 n, ozg_limits lim, u64 *prof) {
 	extern __shared__ __attribute__ ((aligned (16))) u8 otz_smem[];
 	u32 i = blockIdx.x;
 	if (i >= n) {
@@ -32,7 +32,7 @@ otz_inflate_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result 
 	}
 	otz_inflate_lds &L = *reinterpret_cast<otz_inflate_lds *> (otz_smem);
 	ozg_entry e = entries[i];
-	otz_run_inflate (L, src, dst, e, &results[i], lim);
+	otz_run_inflate (L, src, dst, e, &results[i], lim, prof ? prof + 16ull * i : nullptr);
 }
 
 extern "C" __global__ void __launch_bounds__ (256)
@@ -74,6 +74,7 @@ std::mutex g_mu;
 bool g_ready = false;
 int g_device = -1;
 ozg_limits g_limits = { 1000ull, 1024ull * 1024ull };
+u64 *g_prof = nullptr; // diagnostics: per-entry phase cycle counters (ozg_debug_set_profile_buffer)
 thread_local char g_err[256] = "";
 
 struct staging {
@@ -207,7 +208,7 @@ int ozg_decode_batch_device_ex(const void *d_src, uint64_t src_len, void *d_dst,
 	hipStream_t s = (hipStream_t)stream;
 	if (!(batch_flags & OZG_BATCH_NO_DEFLATE)) {
 		hipLaunchKernelGGL (otz_inflate_kernel, dim3 (n), dim3 (256), sizeof (otz_inflate_lds), s, (const u8 *)d_src,
-			(u8 *)d_dst, d_entries, d_results, n, g_limits);
+			(u8 *)d_dst, d_entries, d_results, n, g_limits, g_prof);
 		OZG_HIP (hipGetLastError ());
 	}
 	if (!(batch_flags & OZG_BATCH_ONLY_DEFLATE)) {
@@ -344,6 +345,10 @@ int ozg_stream_sync(void *stream) {
 	OZG_HIP (hipStreamSynchronize ((hipStream_t)stream));
 	return OZG_OK;
 }
+
+/* Diagnostics only: d_buf = n x 16 uint64 device words that the inflate kernel fills with
+ * per-phase cycle counts of every entry (NULL switches it off). */
+void ozg_debug_set_profile_buffer(void *d_buf) { g_prof = (u64 *)d_buf; }
 
 const char *ozg_kernel_name_inflate(void) { return "otz_inflate_kernel"; }
 const char *ozg_kernel_name_copy(void) { return "otz_copy_kernel"; }

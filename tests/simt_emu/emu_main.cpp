@@ -28,7 +28,7 @@ void *thread_main(void *p) {
 	otz_emu_self.tid = a->tid;
 	otz_emu_self.blk = a->blk;
 	if (a->e->method == OZG_METHOD_DEFLATE) {
-		otz_run_inflate (*(otz_inflate_lds *)a->lds, a->src, a->dst, *a->e, a->r, a->lim);
+		otz_run_inflate (*(otz_inflate_lds *)a->lds, a->src, a->dst, *a->e, a->r, a->lim, nullptr);
 	} else {
 		otz_run_copy (*(otz_copy_lds *)a->lds, a->src, a->dst, *a->e, a->r, a->lim);
 	}

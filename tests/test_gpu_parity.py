@@ -87,7 +87,7 @@ def test_full_size_properties(gpu_lib):
         assert b2.results[i].crc32 == r.crc32
     for i in range(0, len(ents), 97):
         e = ents[i]
-        assert b1.data(i) == zlib.decompress(arc[e["data_off"]:e["data_off"] + e["comp_size"], ], -15)
+        assert b1.data(i) == zlib.decompress(arc[e["data_off"]:e["data_off"] + e["comp_size"]], -15)
     assert b1.dst == b2.dst
 
 
