@@ -126,6 +126,8 @@ def main():
     import otezip_amd as oz
     from otezip_amd import _native as N
 
+    # synthetic archive first: the generator forks workers, which must happen before HIP is up
+    arc, ent = load_shard(rank, args.entries, args.entry_size, args.method, args.cache_dir)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: otezip-amd has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -136,7 +138,6 @@ def main():
     oz.init(local_rank)
     L = oz.lib()
 
-    arc, ent = load_shard(rank, args.entries, args.entry_size, args.method, args.cache_dir)
     n = len(ent)
     items = [(int(m), int(off), int(cs), int(us), int(crc)) for m, off, cs, us, crc in ent]
     ents, dst_len = oz.make_entries(items)
