@@ -48,7 +48,7 @@ def main():
     def add(name, method, comp, usize, crc, flags=0, note=""):
         ref = O.ref_extract_entry(method, comp, usize, crc, ignore_zipbomb=flags & 1)
         orc = O.extract_entry(method, comp, usize, crc, ignore_zipbomb=flags & 1)
-        undefined = bool(orc["verdict"] & O.V_REF_UNDEFINED)
+        undefined = bool(orc["verdict"] & O.V_NO_PARITY)
         ref_ok = ref is not None
         correct_ok = orc["correct_rc"] == 0
         if not undefined:

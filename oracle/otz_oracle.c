@@ -55,6 +55,8 @@ typedef struct {
 	int16_t map[65536];
 } otz_codeset;
 
+static int g_oversubscribed; /* set by codeset_build; read and cleared by otz_inflate_raw */
+
 static int codeset_build(otz_codeset *cs, const uint8_t *lengths, int n) {
 	uint16_t bl_count[16];
 	uint16_t next_code[16];
@@ -69,9 +71,15 @@ static int codeset_build(otz_codeset *cs, const uint8_t *lengths, int n) {
 	}
 	uint16_t code = 0;
 	next_code[0] = 0;
+	long left = 1;
 	for (int bits = 1; bits <= 15; bits++) {
 		code = (uint16_t) ((code + bl_count[bits - 1]) << 1);
 		next_code[bits] = code;
+		left = (left << 1) - bl_count[bits];
+		if (left < 0) {
+			g_oversubscribed = 1;
+			left = 0;
+		}
 	}
 	memset (cs->map, 0xFF, sizeof (cs->map));
 	/* ascending symbol order hands out the code values; the first symbol
@@ -260,6 +268,7 @@ otz_codec_result otz_inflate_raw(const uint8_t *in, uint32_t in_len, uint8_t *ou
 	int ref_done = 0; /* reference has already returned */
 	int undef = 0;
 	int ret;
+	g_oversubscribed = 0;
 	otz_codeset *lit = (otz_codeset *)malloc (sizeof (otz_codeset));
 	otz_codeset *dist = (otz_codeset *)malloc (sizeof (otz_codeset));
 	if (!lit || !dist) {
@@ -449,6 +458,9 @@ done:
 	}
 	if (undef) {
 		r.verdict |= OTZ_V_REF_UNDEFINED;
+	}
+	if (g_oversubscribed) {
+		r.verdict |= OTZ_V_OVERSUBSCRIBED;
 	}
 	return r;
 #undef REF_RETURNS

@@ -52,6 +52,10 @@ extern "C" {
 #define OTZ_V_SHORT_STREAM 4u     /* accepted with total_out < uncomp_size:
                                      zero-filled tail */
 #define OTZ_V_CRC_MISMATCH 8u     /* computed CRC != directory CRC */
+#define OTZ_V_OVERSUBSCRIBED 16u  /* a Huffman code set in the stream violates the Kraft inequality:
+                                     malformed input that the reference still "decodes" through its
+                                     first-match symbol search (ref deflate-dec.inc.c:86-119 has no
+                                     check); only accept/reject is comparable (parity rule 4) */
 
 typedef struct {
 	int ret;            /* what the reference codec returns (Z_* code) */

@@ -18,7 +18,8 @@ REF_BENCH = os.path.join(HERE, "_ref", "ref_bench")
 Z_OK, Z_STREAM_END, Z_STREAM_ERROR, Z_DATA_ERROR, Z_MEM_ERROR, Z_BUF_ERROR = 0, 1, -2, -3, -4, -5
 Z_FINISH = 4
 M_STORE, M_DEFLATE, M_LZMA, M_ZSTD, M_BROTLI, M_LZFSE = 0, 8, 14, 93, 97, 100
-V_REF_FALSE_REJECT, V_REF_UNDEFINED, V_SHORT_STREAM, V_CRC_MISMATCH = 1, 2, 4, 8
+V_REF_FALSE_REJECT, V_REF_UNDEFINED, V_SHORT_STREAM, V_CRC_MISMATCH, V_OVERSUBSCRIBED = 1, 2, 4, 8, 16
+V_NO_PARITY = V_REF_UNDEFINED | V_OVERSUBSCRIBED  # malformed input: the new build only has to fail cleanly
 
 
 def build(force=False):

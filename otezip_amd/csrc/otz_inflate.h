@@ -34,16 +34,22 @@
 #include "otz_crc.h"
 #include "../../include/otezip_gpu.h"
 
-#define OTZ_NT 256u
+#ifndef OTZ_NT
+#define OTZ_NT 256u            // work-items per workgroup (4 wavefronts)
+#endif
 #define OTZ_RING 65536u
 #define OTZ_RING_MASK 65535u
-#define OTZ_S_BITS 128u         // speculative subsequence per lane per round
+#ifndef OTZ_S_BITS
+#define OTZ_S_BITS 128u         // speculative subsequence per lane per round (at most 128)
+#endif
 #define OTZ_TOK_CAP 32u         // tokens per pass-A path (bounds lane 0's output)
 #define OTZ_RMAX 16384u         // output bytes per round (size of the final bitmap)
-#define OTZ_STAGE_BYTES 4608u   // 256 lanes * 16 B + skew + lookahead; also holds the CRC tables
+#define OTZ_STAGE_BYTES 4608u   // OTZ_NT * OTZ_S_BITS / 8 = 4096 B + skew + lookahead; also holds the CRC tables
 #define OTZ_STAGE_WORDS (OTZ_STAGE_BYTES / 4)
-#define OTZ_LIT_ROOT 10
+#define OTZ_LIT_ROOT 9          // two-level tables: root + sub-tables for the longer codes
 #define OTZ_DIST_ROOT 8
+#define OTZ_LIT_LUT 1024u       // 512 root entries + room for the sub-tables (zlib's ENOUGH_LENS is 852)
+#define OTZ_DIST_LUT 512u       // 256 root entries + sub-tables (<= 146 for 32 symbols)
 #define OTZ_SPIN_LIMIT 1000000u
 #define OTZ_ST_NEED_OUT_INT (-100) // OZG_ST_NEED_OUT is 0, which L.status uses for "still decoding"
 
@@ -58,8 +64,10 @@
 #define OTZ_X_KIND(x) ((x) >> 24)
 #define OTZ_X_MAKE(kind, pos) (((kind) << 24) | (pos))
 
-// LUT entry: [3:0] code length (0 = longer than the root, or no code),
-// [5:4] kind, [11:8] extra-bit count, [31:16] literal / base length / base distance
+// LUT entry: [3:0] code length, [5:4] kind, [11:8] extra-bit count,
+// [31:16] literal / base length / base distance.
+// Code length 0 marks a root slot without a code of its own: kind OTZ_K_LEN there
+// means "link": [11:8] = index bits of the sub-table, [31:16] = its first slot.
 #define OTZ_K_LIT 0u
 #define OTZ_K_LEN 1u
 #define OTZ_K_EOB 2u
@@ -73,14 +81,8 @@ struct otz_canon {
 
 struct otz_inflate_lds {
 	u8 ring[OTZ_RING];
-	u32 lit_lut[1u << OTZ_LIT_ROOT];
-	u32 dist_lut[1u << OTZ_DIST_ROOT];
-	u16 lit_sorted[288];
-	u16 dist_sorted[32];
-	otz_canon lit_c, dist_c, cl_c;
-	u8 cl_sorted[20];
-	u8 cl_len[20];
-	u32 cl_lut[128];
+	u32 lit_lut[OTZ_LIT_LUT];
+	u32 dist_lut[OTZ_DIST_LUT];
 	union {
 		u32 stage_w[OTZ_STAGE_WORDS];
 		u8 stage[OTZ_STAGE_BYTES];
@@ -88,10 +90,21 @@ struct otz_inflate_lds {
 	};
 	union {
 		u32 fin[OTZ_RMAX / 32]; // pass C: byte is final
-		u32 exits[OTZ_NT];      // pass A/B: per-lane exit word
 		u8 ll[320];             // table build: code lengths
 	};
-	u32 hist[16 * 2]; // code length histograms (lit, dist)
+	union {
+		u32 mstart[OTZ_RMAX / 32]; // pass C: an unresolved match starts at this byte
+		u32 exits[OTZ_NT];         // pass A/B: per-lane exit word
+		struct {                   // header parse + table build only
+			u16 lit_sorted[288];
+			u16 dist_sorted[32];
+			otz_canon lit_c, dist_c, cl_c;
+			u8 cl_sorted[20];
+			u8 cl_len[20];
+			u32 cl_lut[128];
+			u32 hist[16 * 2]; // code length histograms (lit, dist)
+		};
+	};
 	u32 scan[8];      // per-wave partials
 	// workgroup-uniform scalars
 	u32 status;       // 0 while decoding, else (u32) final status code (nonzero ends the entry)
@@ -131,6 +144,7 @@ struct otz_job {
 #define OTZ_P_EMIT 7
 #define OTZ_P_FLUSH 8
 #define OTZ_P_STORED 9
+#define OTZ_P_RESOLVE 10
 #define OTZ_P_ROUNDS 12
 #define OTZ_P_B_ITERS 13
 #define OTZ_P_BLOCKS 14
@@ -249,45 +263,51 @@ struct otz_tok {
 	u32 dist;
 };
 
-// Decode one token (literal / end-of-block / length+distance pair).
-OTZ_DEV otz_tok otz_decode_token(const otz_inflate_lds &L, otz_br &r) {
-	otz_tok t;
-	otz_br_refill (r, L.stage_w);
-	u32 lo = (u32)r.bb;
-	u32 e = L.lit_lut[lo & ((1u << OTZ_LIT_ROOT) - 1u)];
-	if ((e & 15u) == 0u) {
-		u32 l;
-		u32 i = otz_canon_lookup (L.lit_c, lo, OTZ_LIT_ROOT + 1, 15, &l);
-		e = l ? otz_mk_lit_entry (L.lit_sorted[i], l) : (OTZ_K_BAD << 4);
+struct otz_dec {
+	u32 unused;
+};
+OTZ_DEV void otz_dec_load(otz_dec &D, const otz_inflate_lds &L) { D.unused = 0; }
+
+// root lookup, then at most one sub-table lookup
+template <u32 ROOT>
+OTZ_DEV u32 otz_lut2(const u32 *lut, u32 bits) {
+	u32 e = lut[bits & ((1u << ROOT) - 1u)];
+	if ((e & 0x3Fu) == (OTZ_K_LEN << 4)) {
+		e = lut[(e >> 16) + otz_bfe (bits, ROOT, (e >> 8) & 15u)];
 	}
+	return e;
+}
+
+// Decode the token (literal / end-of-block / length+distance pair) that starts at
+// stage-relative bit `pos`.  One LDS round trip fetches 64 stream bits, which
+// always cover a whole token (at most 15+5+15+13 = 48 bits); the table lookups
+// follow.  No state is carried from token to token except `pos`.
+OTZ_DEV otz_tok otz_decode_at(const otz_inflate_lds &L, const otz_dec &D, u32 pos) {
+	otz_tok t;
+	u32 w = pos >> 5, sh = pos & 31u;
+	u32 d0 = L.stage_w[w], d1 = L.stage_w[w + 1], d2 = L.stage_w[w + 2];
+	u32 lo = otz_alignbit (d1, d0, sh), hi = otz_alignbit (d2, d1, sh);
+	u32 e = otz_lut2<OTZ_LIT_ROOT> (L.lit_lut, lo);
 	u32 len = e & 15u;
-	t.kind = (e >> 4) & 3u;
+	t.kind = len ? (e >> 4) & 3u : OTZ_K_BAD;
 	t.val = e >> 16;
 	t.dist = 0;
 	t.nbits = len;
 	if (t.kind != OTZ_K_LEN) {
-		otz_br_drop (r, len);
 		return t;
 	}
 	u32 xb = (e >> 8) & 15u;
-	t.val += (u32) (r.bb >> len) & ((1u << xb) - 1u);
-	otz_br_drop (r, len + xb);
-	otz_br_refill (r, L.stage_w);
-	lo = (u32)r.bb;
-	u32 d = L.dist_lut[lo & ((1u << OTZ_DIST_ROOT) - 1u)];
-	if ((d & 15u) == 0u) {
-		u32 l;
-		u32 i = otz_canon_lookup (L.dist_c, lo, OTZ_DIST_ROOT + 1, 15, &l);
-		d = l ? otz_mk_dist_entry (L.dist_sorted[i], l) : (OTZ_K_BAD << 4);
-	}
-	u32 dl = d & 15u, dxb = (d >> 8) & 15u;
-	if (((d >> 4) & 3u) != OTZ_K_LEN) {
+	t.val += otz_bfe (lo, len, xb);
+	u32 used = len + xb; // <= 20
+	u32 db = otz_alignbit (hi, lo, used);
+	u32 d = otz_lut2<OTZ_DIST_ROOT> (L.dist_lut, db);
+	u32 dl = d & 15u, dxb = (d >> 8) & 15u; // dl + dxb <= 28
+	if (dl == 0 || ((d >> 4) & 3u) != OTZ_K_LEN) {
 		t.kind = OTZ_K_BAD;
 		return t;
 	}
-	t.dist = (d >> 16) + ((u32) (r.bb >> dl) & ((1u << dxb) - 1u));
-	otz_br_drop (r, dl + dxb);
-	t.nbits = len + xb + dl + dxb;
+	t.dist = (d >> 16) + otz_bfe (db, dl, dxb);
+	t.nbits = used + dl + dxb;
 	return t;
 }
 
@@ -469,6 +489,86 @@ OTZ_DEV void otz_sort_syms(const otz_canon &c, const u8 *ll, u32 n, u16 *sorted)
 	}
 }
 
+// Two-level decode table from the canonical bookkeeping + sorted symbols.  All
+// work-items.  Returns false (uniformly) if the sub-tables do not fit, which no
+// code set a compressor emits can cause.
+template <u32 ROOT, u32 CAP, bool LIT>
+OTZ_DEV bool otz_fill_lut(otz_inflate_lds &L, u32 *lut, const otz_canon &c, const u16 *sorted) {
+	const u32 tid = otz_tid ();
+	const u32 RSZ = 1u << ROOT;
+	// root slots of the codes that fit the root; 0 elsewhere
+	for (u32 i = tid; i < CAP; i += OTZ_NT) {
+		u32 e = 0;
+		if (i < RSZ) {
+			u32 l;
+			u32 k = otz_canon_lookup (c, i, 1, ROOT, &l);
+			if (l) {
+				e = LIT ? otz_mk_lit_entry (sorted[k], l) : otz_mk_dist_entry (sorted[k], l);
+			}
+		}
+		lut[i] = e;
+	}
+	otz_sync ();
+	// longer codes: work-item k takes the k-th long symbol (canonical order)
+	const u32 long0 = c.off[ROOT + 1];
+	const u32 nsym = (u32)c.off[15] + c.count[15];
+	const u32 k = long0 + tid;
+	for (u32 kk = k; kk < nsym; kk += OTZ_NT) { // at most 2 trips (288 symbols)
+		u32 ll = ROOT + 1;
+		while (ll < 15 && kk >= (u32)c.off[ll] + c.count[ll]) {
+			ll++;
+		}
+		u32 code = (u32)c.first[ll] + (kk - c.off[ll]);
+		u32 rr = otz_brev (code) >> (32u - ll);
+		otz_lds_max (&lut[rr & (RSZ - 1u)], (ll - ROOT) << 8); // widest code under this root slot
+	}
+	otz_sync ();
+	// sub-table placement: prefix sum of 2^bits over the root slots (RSZ / 256 per work-item)
+	const u32 per = (RSZ + OTZ_NT - 1u) / OTZ_NT;
+	u32 mine = 0;
+	for (u32 j = 0; j < per; j++) {
+		u32 i = tid * per + j;
+		u32 e = i < RSZ ? lut[i] : 0u;
+		if (e && (e & 15u) == 0) {
+			mine += 1u << (e >> 8);
+		}
+	}
+	u32 total;
+	u32 incl = otz_block_scan_incl (mine, L.scan, &total);
+	u32 at = RSZ + incl - mine;
+	if (total <= CAP - RSZ) {
+		for (u32 j = 0; j < per; j++) {
+			u32 i = tid * per + j;
+			u32 e = i < RSZ ? lut[i] : 0u;
+			if (e && (e & 15u) == 0) {
+				u32 sb = e >> 8;
+				lut[i] = (at << 16) | (sb << 8) | (OTZ_K_LEN << 4);
+				at += 1u << sb;
+			}
+		}
+	}
+	otz_sync ();
+	if (total > CAP - RSZ) {
+		return false;
+	}
+	for (u32 kk = k; kk < nsym; kk += OTZ_NT) {
+		u32 ll = ROOT + 1;
+		while (ll < 15 && kk >= (u32)c.off[ll] + c.count[ll]) {
+			ll++;
+		}
+		u32 rr = otz_brev ((u32)c.first[ll] + (kk - c.off[ll])) >> (32u - ll);
+		u32 link = lut[rr & (RSZ - 1u)];
+		u32 sb = (link >> 8) & 15u, base = link >> 16;
+		u32 e = LIT ? otz_mk_lit_entry (sorted[kk], ll) : otz_mk_dist_entry (sorted[kk], ll);
+		u32 step = 1u << (ll - ROOT);
+		for (u32 idx = rr >> ROOT; idx < (1u << sb); idx += step) {
+			lut[base + idx] = e;
+		}
+	}
+	otz_sync ();
+	return true;
+}
+
 // Build both decode tables from L.ll[0..hlit+hdist). All work-items; returns
 // false (uniformly) on an over-subscribed set.
 OTZ_DEV bool otz_build_tables(otz_inflate_lds &L, u32 hlit, u32 hdist) {
@@ -503,18 +603,9 @@ OTZ_DEV bool otz_build_tables(otz_inflate_lds &L, u32 hlit, u32 hdist) {
 		otz_sort_syms (L.dist_c, L.ll + hlit, hdist, L.dist_sorted);
 	}
 	otz_sync ();
-	for (u32 i = tid; i < (1u << OTZ_LIT_ROOT); i += OTZ_NT) {
-		u32 l;
-		u32 k = otz_canon_lookup (L.lit_c, i, 1, OTZ_LIT_ROOT, &l);
-		L.lit_lut[i] = l ? otz_mk_lit_entry (L.lit_sorted[k], l) : 0u;
-	}
-	for (u32 i = tid; i < (1u << OTZ_DIST_ROOT); i += OTZ_NT) {
-		u32 l;
-		u32 k = otz_canon_lookup (L.dist_c, i, 1, OTZ_DIST_ROOT, &l);
-		L.dist_lut[i] = l ? otz_mk_dist_entry (L.dist_sorted[k], l) : 0u;
-	}
-	otz_sync ();
-	return true;
+	bool fits = otz_fill_lut<OTZ_LIT_ROOT, OTZ_LIT_LUT, true> (L, L.lit_lut, L.lit_c, L.lit_sorted);
+	fits = otz_fill_lut<OTZ_DIST_ROOT, OTZ_DIST_LUT, false> (L, L.dist_lut, L.dist_c, L.dist_sorted) && fits;
+	return fits;
 }
 
 // ------------------------------------------------------------ block headers
@@ -659,66 +750,69 @@ struct otz_path {
 #define OTZ_MODE_PREFIX 2 // from the speculative start up to `stop`
 
 template <int MODE>
-OTZ_DEV otz_path otz_walk(const otz_inflate_lds &L, u32 start, u32 s, u32 e, u32 limit_bits, u32 stop, u32 (&vis)[4]) {
+OTZ_DEV otz_path otz_walk(const otz_inflate_lds &L, const otz_dec &D, u32 start, u32 s, u32 e, u32 limit_bits, u32 stop, u32 (&vis)[4]) {
 	otz_path P;
 	P.bytes = 0;
 	P.syncq = ~0u;
-	otz_br r;
-	otz_br_init (r, L.stage_w, start);
+	P.exit = 0;
 	u32 pos = start, ntok = 0;
+	const u32 end = MODE == OTZ_MODE_PREFIX ? stop : e;
+	const bool near_end = e + 64u > limit_bits; // only the lanes at the end of the input check for truncation
+	u32 cw = 0, ck = 0;                         // MODE_A: visited bits of the 32-bit word being filled
 	for (;;) {
-		if (MODE == OTZ_MODE_PREFIX) {
-			if (pos >= stop) {
-				P.exit = OTZ_X_MAKE (OTZ_X_NORMAL, pos);
-				return P;
-			}
-		} else {
-			if (pos >= e) {
-				P.exit = OTZ_X_MAKE (OTZ_X_NORMAL, pos);
-				return P;
-			}
+		if (pos >= end) {
+			P.exit = OTZ_X_MAKE (OTZ_X_NORMAL, pos);
+			break;
 		}
 		u32 rel = pos - s; // pos >= s always (a left neighbour exits at or after s)
 		if (MODE == OTZ_MODE_A) {
 			if (ntok >= OTZ_TOK_CAP) {
 				P.exit = OTZ_X_MAKE (OTZ_X_CUT, pos);
-				return P;
+				break;
 			}
-			u32 bit = 1u << (rel & 31u), k = rel >> 5;
-			vis[0] |= k == 0 ? bit : 0u;
-			vis[1] |= k == 1 ? bit : 0u;
-			vis[2] |= k == 2 ? bit : 0u;
-			vis[3] |= k == 3 ? bit : 0u;
+			u32 k = rel >> 5;
+			if (k != ck) {
+				vis[0] |= ck == 0 ? cw : 0u;
+				vis[1] |= ck == 1 ? cw : 0u;
+				vis[2] |= ck == 2 ? cw : 0u;
+				vis[3] |= ck == 3 ? cw : 0u;
+				cw = 0;
+				ck = k;
+			}
+			cw |= 1u << (rel & 31u);
 		}
 		if (MODE == OTZ_MODE_B) {
 			u32 k = rel >> 5;
 			u32 w = k == 0 ? vis[0] : k == 1 ? vis[1] : k == 2 ? vis[2] : vis[3];
 			if ((w >> (rel & 31u)) & 1u) {
 				P.syncq = pos;
-				return P;
+				break;
 			}
 		}
-		if (pos >= limit_bits) {
-			P.exit = OTZ_X_MAKE (OTZ_X_TRUNC, pos);
-			return P;
-		}
-		otz_tok t = otz_decode_token (L, r);
+		otz_tok t = otz_decode_at (L, D, pos);
 		if (t.kind == OTZ_K_BAD) {
-			P.exit = OTZ_X_MAKE (OTZ_X_INVALID, pos);
-			return P;
+			P.exit = OTZ_X_MAKE (pos >= limit_bits ? OTZ_X_TRUNC : OTZ_X_INVALID, pos);
+			break;
 		}
-		if (pos + t.nbits > limit_bits) {
+		if (near_end && pos + t.nbits > limit_bits) {
 			P.exit = OTZ_X_MAKE (OTZ_X_TRUNC, pos);
-			return P;
+			break;
 		}
 		pos += t.nbits;
 		ntok++;
 		if (t.kind == OTZ_K_EOB) {
 			P.exit = OTZ_X_MAKE (OTZ_X_EOB, pos);
-			return P;
+			break;
 		}
 		P.bytes += t.kind == OTZ_K_LIT ? 1u : t.val;
 	}
+	if (MODE == OTZ_MODE_A) {
+		vis[0] |= ck == 0 ? cw : 0u;
+		vis[1] |= ck == 1 ? cw : 0u;
+		vis[2] |= ck == 2 ? cw : 0u;
+		vis[3] |= ck == 3 ? cw : 0u;
+	}
+	return P;
 }
 
 OTZ_DEV void otz_mark_final(otz_inflate_lds &L, u32 a, u32 b) {
@@ -728,12 +822,16 @@ OTZ_DEV void otz_mark_final(otz_inflate_lds &L, u32 a, u32 b) {
 	}
 	otz_fence_release ();
 	u32 w0 = a >> 5, w1 = (b - 1u) >> 5;
-	for (u32 w = w0; w <= w1; w++) {
-		u32 lo = w == w0 ? (a & 31u) : 0u;
-		u32 hi = w == w1 ? ((b - 1u) & 31u) : 31u;
-		u32 m = (0xFFFFFFFFu >> (31u - hi)) & (0xFFFFFFFFu << lo);
-		otz_lds_or (&L.fin[w], m);
+	u32 mlo = 0xFFFFFFFFu << (a & 31u), mhi = 0xFFFFFFFFu >> (31u - ((b - 1u) & 31u));
+	if (w0 == w1) {
+		otz_lds_or (&L.fin[w0], mlo & mhi);
+		return;
 	}
+	otz_lds_or (&L.fin[w0], mlo);
+	for (u32 w = w0 + 1u; w < w1; w++) {
+		otz_lds_or (&L.fin[w], 0xFFFFFFFFu);
+	}
+	otz_lds_or (&L.fin[w1], mhi);
 }
 
 OTZ_DEV bool otz_all_final(const otz_inflate_lds &L, u32 a, u32 b) {
@@ -741,118 +839,160 @@ OTZ_DEV bool otz_all_final(const otz_inflate_lds &L, u32 a, u32 b) {
 		return true;
 	}
 	u32 w0 = a >> 5, w1 = (b - 1u) >> 5;
-	for (u32 w = w0; w <= w1; w++) {
-		u32 lo = w == w0 ? (a & 31u) : 0u;
-		u32 hi = w == w1 ? ((b - 1u) & 31u) : 31u;
-		u32 m = (0xFFFFFFFFu >> (31u - hi)) & (0xFFFFFFFFu << lo);
-		if ((otz_lds_load (&L.fin[w]) & m) != m) {
-			return false;
+	u32 mlo = 0xFFFFFFFFu << (a & 31u), mhi = 0xFFFFFFFFu >> (31u - ((b - 1u) & 31u));
+	bool ok;
+	if (w0 == w1) {
+		u32 m = mlo & mhi;
+		ok = (otz_lds_load (&L.fin[w0]) & m) == m;
+	} else {
+		ok = (otz_lds_load (&L.fin[w0]) & mlo) == mlo && (otz_lds_load (&L.fin[w1]) & mhi) == mhi;
+		for (u32 w = w0 + 1u; ok && w < w1; w++) {
+			ok = otz_lds_load (&L.fin[w]) == 0xFFFFFFFFu;
 		}
 	}
 	otz_fence_acquire ();
-	return true;
+	return ok;
 }
 
-// Pass C: every lane decodes its tokens again from its true start and
-// materialises them.  All 64 lanes of a wavefront stay in ONE loop and take at
-// most one step per trip; the ballot at the bottom is a convergent operation, so
-// the compiler cannot peel the "wait for another lane's bytes" path into an inner
-// loop (which would park the very lanes being waited for: SIMT deadlock).
-// Call from wave-uniform control flow; lanes with active == false just vote.
-OTZ_DEV void otz_emit(otz_inflate_lds &L, bool active, u32 start, u32 exit_word, u32 o, u32 round_base, u64 stage_abs_bit) {
+// Pass C1 ("place"): every lane decodes its tokens again from its true start.
+// Literals go straight to their final bytes.  A match is NOT copied here: its 23
+// bits (distance-1 : 15, length-3 : 8) are parked in the first three bytes of its
+// own destination (a match is at least three bytes long, so the space is always
+// there), and the destination's bit is set in the match-start bitmap.  No lane
+// waits for another lane in this pass.
+OTZ_DEV void otz_place(otz_inflate_lds &L, const otz_dec &D, bool active, u32 start, u32 exit_word, u32 o, u32 round_base, u64 stage_abs_bit) {
+	if (!active) {
+		return;
+	}
 	u32 exit_pos = OTZ_X_POS (exit_word);
-	otz_br r;
-	otz_br_init (r, L.stage_w, active ? start : 0u);
-	u32 pos = start, run_start = o, pend = 0, pdist = 0, spins = 0;
-	bool ready = false, done = !active;
+	u32 pos = start, run_start = o;
+	while (pos < exit_pos) {
+		otz_tok t = otz_decode_at (L, D, pos);
+		u32 tpos = pos;
+		pos += t.nbits;
+		if (t.kind == OTZ_K_LIT) {
+			L.ring[o & OTZ_RING_MASK] = (u8)t.val;
+			o++;
+			continue;
+		}
+		otz_mark_final (L, run_start - round_base, o - round_base);
+		if (t.kind == OTZ_K_EOB) {
+			u64 a = stage_abs_bit + tpos;
+			L.eob_start_lo = (u32)a;
+			L.eob_start_hi = (u32) (a >> 32);
+			return;
+		}
+		if (t.kind != OTZ_K_LEN) {
+			L.dbg[0] = 2; // validated path cannot hold a bad token
+			L.dbg[1] = otz_tid ();
+			L.dbg[2] = tpos;
+			L.dbg[3] = t.kind | (t.nbits << 8);
+			otz_set_status (L, OZG_ST_INTERNAL);
+			return;
+		}
+		if (t.dist > o) {
+			// ref reads window bytes nobody wrote (:524): no parity, fail cleanly
+			otz_set_status (L, OZG_ST_DATA);
+			return;
+		}
+		u32 d = (t.dist - 1u) | ((t.val - 3u) << 15);
+		L.ring[o & OTZ_RING_MASK] = (u8)d;
+		L.ring[(o + 1u) & OTZ_RING_MASK] = (u8) (d >> 8);
+		L.ring[(o + 2u) & OTZ_RING_MASK] = (u8) (d >> 16);
+		u32 rel = o - round_base;
+		otz_lds_or (&L.mstart[rel >> 5], 1u << (rel & 31u));
+		o += t.val;
+		run_start = o;
+	}
+	otz_mark_final (L, run_start - round_base, o - round_base);
+}
+
+// Pass C2 ("resolve"): the LZ77 copies, all lanes at once.  Lane j owns the
+// matches that START in bytes [32j, 32j+32) and [32(j+256), ...) of the round's
+// output; it keeps trying its pending matches round-robin and copies one as soon
+// as every source byte is final (literal, older round, or an already resolved
+// match).  The earliest unresolved match of the round is always ready, so the
+// loop cannot stall.  One loop per wavefront, closed by a ballot: a convergent
+// operation keeps the compiler from peeling the "not ready yet" path into an
+// inner loop, which would park the lanes being waited for (SIMT deadlock).
+OTZ_DEV void otz_resolve(otz_inflate_lds &L, u32 round_base, u32 round_bytes) {
+	const u32 nwords = (round_bytes + 31u) >> 5;
+	u32 w = otz_tid ();
+	u32 pending = w < nwords ? L.mstart[w] : 0u;
+	u32 cand = pending;
+	u32 o = 0, pend = 0, pdist = 0, spins = 0;
+	bool done = false;
 	for (;;) {
 		bool progressed = false;
 		if (!done && pend == 0) {
-			progressed = true;
-			if (pos >= exit_pos) {
-				otz_mark_final (L, run_start - round_base, o - round_base);
-				done = true;
-			} else {
-				otz_tok t = otz_decode_token (L, r);
-				u32 tpos = pos;
-				pos += t.nbits;
-				if (t.kind == OTZ_K_LIT) {
-					L.ring[o & OTZ_RING_MASK] = (u8)t.val;
-					o++;
+			if (pending == 0) {
+				w += OTZ_NT;
+				if (w < nwords) {
+					pending = L.mstart[w];
+					cand = pending;
+					progressed = true;
 				} else {
-					otz_mark_final (L, run_start - round_base, o - round_base);
-					run_start = o;
-					if (t.kind == OTZ_K_EOB) {
-						u64 a = stage_abs_bit + tpos;
-						L.eob_start_lo = (u32)a;
-						L.eob_start_hi = (u32) (a >> 32);
-						done = true;
-					} else if (t.kind != OTZ_K_LEN) {
-						L.dbg[0] = 2; // validated path cannot hold a bad token
-						L.dbg[1] = otz_tid ();
-						L.dbg[2] = tpos;
-						L.dbg[3] = t.kind | (t.nbits << 8);
-						otz_set_status (L, OZG_ST_INTERNAL);
-						done = true;
-					} else if (t.dist > o) {
-						// ref reads window bytes nobody wrote (:524): no parity, fail cleanly
-						otz_set_status (L, OZG_ST_DATA);
-						done = true;
-					} else {
-						pend = t.val;
-						pdist = t.dist;
-						ready = false;
-					}
+					done = true;
+				}
+			} else {
+				if (cand == 0) {
+					cand = pending;
+				}
+				u32 b = otz_ctz (cand);
+				cand &= cand - 1u;
+				u32 at = round_base + 32u * w + b;
+				u32 d = (u32)L.ring[at & OTZ_RING_MASK] | ((u32)L.ring[(at + 1u) & OTZ_RING_MASK] << 8) |
+					((u32)L.ring[(at + 2u) & OTZ_RING_MASK] << 16);
+				u32 dist = (d & 0x7FFFu) + 1u, len = (d >> 15) + 3u;
+				u32 s0 = at - dist;
+				u32 e0 = s0 + (len < dist ? len : dist);
+				bool ready = e0 <= round_base;
+				if (!ready) {
+					u32 a = s0 > round_base ? s0 - round_base : 0u;
+					ready = otz_all_final (L, a, e0 - round_base);
+				}
+				if (ready) {
+					o = at;
+					pend = len;
+					pdist = dist;
+					pending &= ~(1u << b);
+				} else if (otz_get_status (L) != 0) {
+					done = true;
+				} else if (++spins > OTZ_SPIN_LIMIT) {
+					L.dbg[0] = 3; // waited too long for source bytes
+					L.dbg[1] = otz_tid ();
+					L.dbg[2] = at;
+					L.dbg[3] = dist | (len << 16);
+					otz_set_status (L, OZG_ST_INTERNAL);
+					done = true;
 				}
 			}
 		}
 		if (!done && pend != 0) {
-			if (!ready) {
-				u32 s0 = o - pdist;
-				u32 e0 = s0 + (pend < pdist ? pend : pdist);
-				if (e0 <= round_base) {
-					ready = true;
-				} else {
-					u32 a = s0 > round_base ? s0 - round_base : 0u;
-					ready = otz_all_final (L, a, e0 - round_base);
-				}
-			}
-			if (ready) {
-				progressed = true;
-				u32 n = pend < 8u ? pend : 8u;
-				if (pdist >= n) {
-					u8 tmp[8];
+			progressed = true;
+			u32 n = pend < 8u ? pend : 8u;
+			if (pdist >= n) {
+				u8 tmp[8];
 #pragma unroll
-					for (u32 k = 0; k < 8; k++) {
-						if (k < n) {
-							tmp[k] = L.ring[(o - pdist + k) & OTZ_RING_MASK];
-						}
-					}
-#pragma unroll
-					for (u32 k = 0; k < 8; k++) {
-						if (k < n) {
-							L.ring[(o + k) & OTZ_RING_MASK] = tmp[k];
-						}
-					}
-				} else {
-					for (u32 k = 0; k < n; k++) {
-						L.ring[(o + k) & OTZ_RING_MASK] = L.ring[(o + k - pdist) & OTZ_RING_MASK];
+				for (u32 k = 0; k < 8; k++) {
+					if (k < n) {
+						tmp[k] = L.ring[(o - pdist + k) & OTZ_RING_MASK];
 					}
 				}
-				otz_mark_final (L, o - round_base, o + n - round_base);
-				o += n;
-				pend -= n;
-				run_start = o;
-			} else if (otz_get_status (L) != 0) {
-				done = true;
-			} else if (++spins > OTZ_SPIN_LIMIT) {
-				L.dbg[0] = 3; // waited too long for source bytes
-				L.dbg[1] = otz_tid ();
-				L.dbg[2] = o;
-				L.dbg[3] = pdist | (pend << 16);
-				otz_set_status (L, OZG_ST_INTERNAL);
-				done = true;
+#pragma unroll
+				for (u32 k = 0; k < 8; k++) {
+					if (k < n) {
+						L.ring[(o + k) & OTZ_RING_MASK] = tmp[k];
+					}
+				}
+			} else {
+				for (u32 k = 0; k < n; k++) {
+					L.ring[(o + k) & OTZ_RING_MASK] = L.ring[(o + k - pdist) & OTZ_RING_MASK];
+				}
 			}
+			otz_mark_final (L, o - round_base, o + n - round_base);
+			o += n;
+			pend -= n;
 		}
 		u64 alive = otz_ballot (!done);
 		u64 moved = otz_ballot (progressed);
@@ -1023,6 +1163,8 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 			}
 		}
 
+		otz_dec D;
+		otz_dec_load (D, L);
 		OTZ_MARK (L, J, OTZ_P_TABLES);
 		// ---- rounds over the block's symbols
 		bool block_done = false;
@@ -1050,7 +1192,7 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 			// pass A
 			const u32 s = p0 + tid * OTZ_S_BITS, e = s + OTZ_S_BITS;
 			u32 vis[4] = { 0, 0, 0, 0 };
-			otz_path A = otz_walk<OTZ_MODE_A> (L, s, s, e, limit_bits, 0, vis);
+			otz_path A = otz_walk<OTZ_MODE_A> (L, D, s, s, e, limit_bits, 0, vis);
 			L.exits[tid] = A.exit;
 			otz_sync ();
 
@@ -1076,7 +1218,7 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 				}
 				if (tid && OTZ_X_KIND (prev) == OTZ_X_NORMAL && OTZ_X_POS (prev) != t) {
 					t = OTZ_X_POS (prev);
-					otz_path B = otz_walk<OTZ_MODE_B> (L, t, s, e, limit_bits, 0, vis);
+					otz_path B = otz_walk<OTZ_MODE_B> (L, D, t, s, e, limit_bits, 0, vis);
 					wbytes = B.bytes;
 					q = B.syncq;
 					u32 ne = q != ~0u ? A.exit : B.exit;
@@ -1106,7 +1248,7 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 					u32 pre = 0;
 					if (q != s) {
 						u32 dummy[4] = { 0, 0, 0, 0 };
-						pre = otz_walk<OTZ_MODE_PREFIX> (L, s, s, e, limit_bits, q, dummy).bytes;
+						pre = otz_walk<OTZ_MODE_PREFIX> (L, D, s, s, e, limit_bits, q, dummy).bytes;
 					}
 					bytes = wbytes + A.bytes - pre;
 				}
@@ -1159,11 +1301,18 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 			// pass C
 			for (u32 i = tid; i < OTZ_RMAX / 32; i += OTZ_NT) {
 				L.fin[i] = 0;
+				L.mstart[i] = 0;
 			}
 			otz_sync ();
-			otz_emit (L, tid < K, tid == 0 ? s : t, my_exit, opos + incl - bytes, opos, stage_abs);
+			otz_place (L, D, tid < K, tid == 0 ? s : t, my_exit, opos + incl - bytes, opos, stage_abs);
 			otz_sync ();
 			OTZ_MARK (L, J, OTZ_P_EMIT);
+			if (otz_get_status (L) != 0) {
+				break;
+			}
+			otz_resolve (L, opos, produced);
+			otz_sync ();
+			OTZ_MARK (L, J, OTZ_P_RESOLVE);
 			if (otz_get_status (L) != 0) {
 				break;
 			}

@@ -1,6 +1,6 @@
 // otz_kernels.hip -- gfx950 kernels and the ozg_* C ABI (include/otezip_gpu.h).
 //
-// Two kernels, one workgroup (256 lanes = 4 wavefronts) per archive entry:
+// Two kernels, one workgroup per archive entry (256 lanes = 4 wavefronts):
 //   otz_inflate_kernel  DEFLATE entries; 79 KB of LDS per workgroup -> two
 //                       resident workgroups per CU (160 KB LDS), 512 entries in
 //                       flight on the chip
@@ -23,7 +23,9 @@ static_assert (sizeof (ozg_entry) == 32, "ozg_entry ABI");
 static_assert (sizeof (ozg_result) == 16, "ozg_result ABI");
 static_assert (sizeof (otz_inflate_lds) <= 80 * 1024, "two inflate workgroups per CU");
 
-extern "C" __global__ void __launch_bounds__ (256)
+static_assert (OTZ_NT * OTZ_S_BITS / 8 + 512 <= OTZ_STAGE_BYTES, "stage must cover one round of input");
+
+extern "C" __global__ void __launch_bounds__ (OTZ_NT)
 otz_inflate_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *results, u32 n, ozg_limits lim, u64 *prof) {
 	extern __shared__ __attribute__ ((aligned (16))) u8 otz_smem[];
 	u32 i = blockIdx.x;
@@ -207,7 +209,7 @@ int ozg_decode_batch_device_ex(const void *d_src, uint64_t src_len, void *d_dst,
 	}
 	hipStream_t s = (hipStream_t)stream;
 	if (!(batch_flags & OZG_BATCH_NO_DEFLATE)) {
-		hipLaunchKernelGGL (otz_inflate_kernel, dim3 (n), dim3 (256), sizeof (otz_inflate_lds), s, (const u8 *)d_src,
+		hipLaunchKernelGGL (otz_inflate_kernel, dim3 (n), dim3 (OTZ_NT), sizeof (otz_inflate_lds), s, (const u8 *)d_src,
 			(u8 *)d_dst, d_entries, d_results, n, g_limits, g_prof);
 		OZG_HIP (hipGetLastError ());
 	}

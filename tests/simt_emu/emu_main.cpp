@@ -41,9 +41,9 @@ extern "C" int emu_decode_batch(const void *src, uint64_t src_len, void *dst, ui
 	const ozg_entry *entries, ozg_result *results, uint32_t n, uint64_t ratio, uint64_t slack) {
 	(void)src_len;
 	(void)dst_len;
-	const u32 NT = 256;
 	size_t lds_bytes = sizeof (otz_inflate_lds) > sizeof (otz_copy_lds) ? sizeof (otz_inflate_lds) : sizeof (otz_copy_lds);
 	for (uint32_t i = 0; i < n; i++) {
+		const u32 NT = entries[i].method == OZG_METHOD_DEFLATE ? OTZ_NT : OTZ_CNT;
 		otz_emu_block blk;
 		blk.nthreads = NT;
 		pthread_barrier_init (&blk.block_bar, nullptr, NT);

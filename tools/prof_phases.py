@@ -11,7 +11,7 @@ import torch
 import otezip_amd as oz
 from otezip_amd import corpus, _native as N
 
-NAMES = ["header", "lengths", "tables", "stage", "passA", "passB", "scan", "emit", "flush", "stored", "-", "-",
+NAMES = ["header", "lengths", "tables", "stage", "passA", "passB", "scan", "place", "flush", "stored", "resolve", "-",
          "rounds#", "B_iters#", "blocks#", "total"]
 
 
