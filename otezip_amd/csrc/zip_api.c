@@ -1,0 +1,864 @@
+/* zip_api.c -- the libzip-subset host API of otezip (include/otezip/zip.h) in
+ * plain C on top of the ozg_* GPU ABI (include/otezip_gpu.h).
+ *
+ * Mirrors the reference's public functions one for one (ref
+ * src/lib/otezip.c:693-785, :1079-1237, :1273-1440, :1592-1667) and its container
+ * plumbing (EOCD / central directory reader :199-396, LFH/CDH/EOCD writer
+ * :1443-1590).  What is NOT here is a codec: every payload goes through the GPU.
+ *
+ * The one structural change is batching.  The reference decodes one entry per
+ * zip_fopen_index() call; a GPU only pays off on batches, and after zip_open the
+ * whole directory is known (method, sizes, CRC, offset of every entry).  So the
+ * first zip_fopen_index(i) outside the cached window reads the compressed bytes
+ * of a run of consecutive entries starting at i with one fread, decodes the run
+ * with ONE ozg_decode_batch_host() call and keeps the outputs; the following
+ * calls are served from that window.  zip_file_t keeps the reference's public
+ * prefix {data,size,pos}; zip_fclose releases the window when its last reader
+ * goes away.
+ */
+#define _GNU_SOURCE
+#include <otezip/zip.h>
+#include <otezip_gpu.h>
+
+#include <sys/stat.h>
+#include <unistd.h>
+
+#define SIG_LFH 0x04034b50u
+#define SIG_CDH 0x02014b50u
+#define SIG_EOCD 0x06054b50u
+#define MAX_PAYLOAD (2ULL * 1024ULL * 1024ULL * 1024ULL) /* ref otezip.c:102 */
+#define MAX_FIELD_LEN (64u * 1024u - 1u)
+
+/* window limits: entries, compressed bytes, output bytes per GPU batch */
+#define WIN_MAX_ENTRIES 8192u
+#define WIN_MAX_COMP (256ull << 20)
+#define WIN_MAX_OUT (1024ull << 20)
+
+int otezip_verify_crc = 0;
+uint64_t otezip_max_expansion_ratio = 1000ULL;
+uint64_t otezip_max_expansion_slack = 1024ULL * 1024ULL;
+int otezip_ignore_zipbomb = 0;
+
+struct window {
+	zip_uint64_t first, count; /* entries [first, first+count) */
+	uint8_t *out;              /* outputs, entry k at out + off[k] */
+	uint64_t *off;
+	ozg_result *res;
+	uint8_t *valid;            /* 0: failed the pre-checks of ref :411-446 */
+	long readers;              /* open zip_file_t that point into out */
+	int detached;              /* no longer the archive's current window */
+};
+
+struct ozh_zip {
+	struct zip pub; /* MUST stay first: callers see this prefix */
+	struct window *win;
+	int gpu_ready;
+};
+
+struct ozh_file {
+	struct zip_file pub; /* MUST stay first */
+	struct window *win;  /* NULL: pub.data is a private heap copy */
+};
+
+static int g_gpu_state; /* 0 untried, 1 ok, -1 failed */
+
+static int gpu_up(void) {
+	if (g_gpu_state == 0) {
+		const char *dev = getenv ("OTEZIP_GPU_DEVICE");
+		int rc = ozg_init (dev ? atoi (dev) : 0);
+		if (rc != OZG_OK) {
+			fprintf (stderr, "otezip-amd: %s\n", ozg_last_error ());
+			g_gpu_state = -1;
+		} else {
+			g_gpu_state = 1;
+		}
+	}
+	return g_gpu_state == 1;
+}
+
+/* ------------------------------------------------------------ small helpers */
+
+static uint16_t rd16(const uint8_t *p) { return otezip_read_le16 (p); }
+static uint32_t rd32(const uint8_t *p) { return otezip_read_le32 (p); }
+
+static int read_fully(FILE *fp, void *dst, size_t n) { return fread (dst, 1, n, fp) == n ? 0 : -1; }
+
+static void dostime_now(uint16_t *t, uint16_t *d) {
+	/* same encoding and clamping as ref src/lib/time.inc.c:29-70 */
+	time_t now = time (NULL);
+	struct tm tmv;
+	if (now == (time_t)-1 || !localtime_r (&now, &tmv)) {
+		*t = 0;
+		*d = (uint16_t) ((1 << 5) | 1);
+		return;
+	}
+	int yo = tmv.tm_year + 1900 - 1980;
+	yo = yo < 0 ? 0 : yo > 127 ? 127 : yo;
+	*t = (uint16_t) ((tmv.tm_hour << 11) | (tmv.tm_min << 5) | ((tmv.tm_sec > 59 ? 59 : tmv.tm_sec) / 2));
+	*d = (uint16_t) ((yo << 9) | ((tmv.tm_mon + 1) << 5) | tmv.tm_mday);
+}
+
+int otezip_method_from_string(const char *name) {
+	static const struct {
+		const char *n;
+		int m;
+	} tab[] = { { "store", OTEZIP_METHOD_STORE }, { "deflate", OTEZIP_METHOD_DEFLATE }, { "zstd", OTEZIP_METHOD_ZSTD },
+		{ "lzma", OTEZIP_METHOD_LZMA }, { "brotli", OTEZIP_METHOD_BROTLI }, { "lzfse", OTEZIP_METHOD_LZFSE } };
+	if (!name) {
+		return -1;
+	}
+	for (size_t i = 0; i < sizeof (tab) / sizeof (tab[0]); i++) {
+		if (!strcmp (name, tab[i].n)) {
+			return tab[i].m;
+		}
+	}
+	return -1;
+}
+
+/* ------------------------------------------------ central directory reader */
+
+#define ERR_READ (-1)
+#define ERR_INCONS (-2)
+
+/* ref otezip_find_eocd, otezip.c:199-272: last EOCD signature whose directory
+ * lies inside the file and starts with a CDH signature */
+static long find_eocd(FILE *fp, size_t *cd_size, uint32_t *cd_ofs, uint16_t *n_entries) {
+	if (fseek (fp, 0, SEEK_END) != 0) {
+		return ERR_READ;
+	}
+	long fsz = ftell (fp);
+	if (fsz < 22) {
+		return ERR_INCONS;
+	}
+	size_t span = fsz < 0x10000 + 22 ? (size_t)fsz : 0x10000 + 22;
+	uint8_t *buf = (uint8_t *)malloc (span);
+	if (!buf) {
+		return ERR_READ;
+	}
+	if (fseek (fp, fsz - (long)span, SEEK_SET) != 0 || read_fully (fp, buf, span) != 0) {
+		free (buf);
+		return ERR_READ;
+	}
+	long found = ERR_INCONS;
+	for (size_t i = span - 22 + 1; i-- > 0;) {
+		if (rd32 (buf + i) != SIG_EOCD) {
+			continue;
+		}
+		uint16_t n = rd16 (buf + i + 10);
+		uint32_t sz = rd32 (buf + i + 12), ofs = rd32 (buf + i + 16);
+		if (ofs > (uint32_t)fsz || (uint64_t)ofs + sz > (uint64_t)fsz) {
+			continue;
+		}
+		if (n > 0 && sz >= 4) {
+			uint8_t sig[4];
+			if (fseek (fp, (long)ofs, SEEK_SET) != 0 || read_fully (fp, sig, 4) != 0 || rd32 (sig) != SIG_CDH) {
+				continue;
+			}
+		}
+		*n_entries = n;
+		*cd_size = sz;
+		*cd_ofs = ofs;
+		found = fsz - (long)span + (long)i;
+		break;
+	}
+	free (buf);
+	return found;
+}
+
+/* ref otezip_load_central, otezip.c:275-396 */
+static int load_central(zip_t *za) {
+	size_t cd_size = 0;
+	uint32_t cd_ofs = 0;
+	uint16_t n = 0;
+	long pos = find_eocd (za->fp, &cd_size, &cd_ofs, &n);
+	if (pos < 0) {
+		return (int)pos;
+	}
+	if (n == 0) {
+		if (cd_size != 0) {
+			return ERR_INCONS;
+		}
+		za->entries = NULL;
+		za->n_entries = 0;
+		return 0;
+	}
+	if (cd_size > MAX_PAYLOAD || (size_t)n * 46 > cd_size) {
+		return ERR_INCONS;
+	}
+	uint8_t *cd = (uint8_t *)malloc (cd_size);
+	if (!cd) {
+		return ERR_READ;
+	}
+	if (fseek (za->fp, (long)cd_ofs, SEEK_SET) != 0 || read_fully (za->fp, cd, cd_size) != 0) {
+		free (cd);
+		return ERR_READ;
+	}
+	za->entries = (struct otezip_entry *)calloc (n, sizeof (struct otezip_entry));
+	if (!za->entries) {
+		free (cd);
+		return ERR_READ;
+	}
+	za->n_entries = n;
+	size_t off = 0;
+	for (uint16_t i = 0; i < n; i++) {
+		if (off + 46 > cd_size || rd32 (cd + off) != SIG_CDH) {
+			free (cd);
+			return ERR_INCONS;
+		}
+		const uint8_t *h = cd + off;
+		size_t nlen = rd16 (h + 28), total = 46 + nlen + rd16 (h + 30) + rd16 (h + 32);
+		if (total > cd_size - off) {
+			free (cd);
+			return ERR_INCONS;
+		}
+		struct otezip_entry *e = &za->entries[i];
+		e->method = rd16 (h + 10);
+		e->file_time = rd16 (h + 12);
+		e->file_date = rd16 (h + 14);
+		e->crc32 = rd32 (h + 16);
+		e->comp_size = rd32 (h + 20);
+		e->uncomp_size = rd32 (h + 24);
+		e->external_attr = rd32 (h + 38);
+		e->local_hdr_ofs = rd32 (h + 42);
+		if (e->comp_size > MAX_PAYLOAD || e->uncomp_size > MAX_PAYLOAD) {
+			free (cd);
+			return ERR_INCONS;
+		}
+		e->name = (char *)malloc (nlen + 1);
+		if (!e->name) {
+			free (cd);
+			return ERR_READ;
+		}
+		memcpy (e->name, h + 46, nlen);
+		e->name[nlen] = 0;
+		off += total;
+	}
+	free (cd);
+	return 0;
+}
+
+/* ------------------------------------------------------------- open / close */
+
+zip_t *zip_open(const char *path, int flags, int *errorp) {
+	/* ref otezip.c:693-785 */
+	struct ozh_zip *z = (struct ozh_zip *)calloc (1, sizeof (*z));
+	if (!z) {
+		if (errorp) {
+			*errorp = -1;
+		}
+		return NULL;
+	}
+	zip_t *za = &z->pub;
+	const char *mode = "rb";
+	int exists = 0;
+	if (flags & ZIP_CREATE) {
+		if ((flags & ZIP_EXCL) && (flags & ZIP_TRUNCATE)) {
+			if (errorp) {
+				*errorp = -1;
+			}
+			free (z);
+			return NULL;
+		}
+		FILE *t = fopen (path, "rb");
+		exists = t != NULL;
+		if (t) {
+			fclose (t);
+		}
+		if (exists && (flags & ZIP_EXCL)) {
+			if (errorp) {
+				*errorp = -1;
+			}
+			free (z);
+			return NULL;
+		}
+		mode = (exists && !(flags & ZIP_TRUNCATE)) ? "r+b" : "w+b";
+		za->mode = 1;
+	}
+	if (mode[0] == 'w') {
+		unlink (path);
+	}
+	za->fp = fopen (path, mode);
+	if (!za->fp) {
+		if (errorp) {
+			*errorp = ZIP_ER_OPEN;
+		}
+		free (z);
+		return NULL;
+	}
+	if (za->mode == 0 || (exists && !(flags & ZIP_TRUNCATE))) {
+		int rc = load_central (za);
+		if (rc != 0) {
+			if (errorp) {
+				*errorp = rc == ERR_READ ? ZIP_ER_READ : rc == ERR_INCONS ? ZIP_ER_INCONS : ZIP_ER_NOZIP;
+			}
+			zip_close (za);
+			return NULL;
+		}
+		if (za->mode == 1) {
+			za->next_index = za->n_entries;
+			/* append: new local headers go where the old central directory started.
+			 * (the reference keeps writing after it, ref :758-779, leaving a dead
+			 * directory in the middle of the file; both layouts are valid ZIP) */
+			fseek (za->fp, 0, SEEK_END);
+		}
+	}
+	if (errorp) {
+		*errorp = 0;
+	}
+	return za;
+}
+
+zip_t *zip_open_from_source(zip_source_t *src, int flags, zip_error_t *error) {
+	/* ref otezip.c:1406-1440: spill the buffer to a temp file, open that */
+	(void)error;
+	if (!src) {
+		return NULL;
+	}
+	char tmp[] = "/tmp/otezip_XXXXXX";
+	mode_t um = umask (077);
+	int fd = mkstemp (tmp);
+	umask (um);
+	if (fd < 0) {
+		return NULL;
+	}
+	ssize_t w = write (fd, src->buf, (size_t)src->len);
+	close (fd);
+	if (w < 0 || (zip_uint64_t)w != src->len) {
+		unlink (tmp);
+		return NULL;
+	}
+	int err = 0;
+	zip_t *za = zip_open (tmp, flags, &err);
+	if (!za) {
+		unlink (tmp);
+	}
+	return za;
+}
+
+static void window_free(struct window *w) {
+	if (!w) {
+		return;
+	}
+	free (w->out);
+	free (w->off);
+	free (w->res);
+	free (w->valid);
+	free (w);
+}
+
+static void window_detach(struct window *w) {
+	if (!w) {
+		return;
+	}
+	if (w->readers == 0) {
+		window_free (w);
+	} else {
+		w->detached = 1;
+	}
+}
+
+static void put16(uint8_t *p, uint16_t v) { otezip_write_le16 (p, v); }
+static void put32(uint8_t *p, uint32_t v) { otezip_write_le32 (p, v); }
+
+static uint32_t write_lfh(FILE *fp, const struct otezip_entry *e) {
+	/* ref otezip.c:1443-1491 */
+	size_t nl = strlen (e->name);
+	if (nl > MAX_FIELD_LEN) {
+		nl = MAX_FIELD_LEN;
+	}
+	uint8_t h[30];
+	put32 (h, SIG_LFH);
+	put16 (h + 4, 20);
+	put16 (h + 6, 0);
+	put16 (h + 8, e->method);
+	put16 (h + 10, e->file_time);
+	put16 (h + 12, e->file_date);
+	put32 (h + 14, e->crc32);
+	put32 (h + 18, e->comp_size);
+	put32 (h + 22, e->uncomp_size);
+	put16 (h + 26, (uint16_t)nl);
+	put16 (h + 28, 0);
+	fwrite (h, 1, 30, fp);
+	fwrite (e->name, 1, nl, fp);
+	return 30 + (uint32_t)nl;
+}
+
+static int finalize(zip_t *za) {
+	/* ref otezip.c:1240-1271, :1494-1590 */
+	long cd_ofs = ftell (za->fp);
+	if (cd_ofs < 0 || (uint64_t)cd_ofs > UINT32_MAX) {
+		return -1;
+	}
+	uint64_t cd_size = 0;
+	for (zip_uint64_t i = 0; i < za->n_entries; i++) {
+		const struct otezip_entry *e = &za->entries[i];
+		size_t nl = strlen (e->name);
+		if (nl > MAX_FIELD_LEN) {
+			nl = MAX_FIELD_LEN;
+		}
+		uint8_t h[46];
+		memset (h, 0, sizeof (h));
+		put32 (h, SIG_CDH);
+		put16 (h + 4, 0x031e);
+		put16 (h + 6, 20);
+		put16 (h + 10, e->method);
+		put16 (h + 12, e->file_time);
+		put16 (h + 14, e->file_date);
+		put32 (h + 16, e->crc32);
+		put32 (h + 20, e->comp_size);
+		put32 (h + 24, e->uncomp_size);
+		put16 (h + 28, (uint16_t)nl);
+		put32 (h + 38, e->external_attr);
+		put32 (h + 42, e->local_hdr_ofs);
+		fwrite (h, 1, 46, za->fp);
+		fwrite (e->name, 1, nl, za->fp);
+		cd_size += 46 + nl;
+		if (cd_size > UINT32_MAX) {
+			return -1;
+		}
+	}
+	uint8_t eocd[22];
+	memset (eocd, 0, sizeof (eocd));
+	put32 (eocd, SIG_EOCD);
+	put16 (eocd + 8, (uint16_t)za->n_entries);
+	put16 (eocd + 10, (uint16_t)za->n_entries);
+	put32 (eocd + 12, (uint32_t)cd_size);
+	put32 (eocd + 16, (uint32_t)cd_ofs);
+	fwrite (eocd, 1, 22, za->fp);
+	return 0;
+}
+
+int zip_close(zip_t *za) {
+	/* ref otezip.c:1273-1295 */
+	if (!za || !za->fp) {
+		free (za);
+		return -1;
+	}
+	struct ozh_zip *z = (struct ozh_zip *)za;
+	if (za->mode == 1) {
+		finalize (za);
+	}
+	fclose (za->fp);
+	for (zip_uint64_t i = 0; i < za->n_entries; i++) {
+		free (za->entries[i].name);
+	}
+	free (za->entries);
+	window_detach (z->win);
+	free (z);
+	return 0;
+}
+
+/* --------------------------------------------------------------- directory */
+
+static int valid(const zip_t *za) { return za != NULL && za->fp != NULL; }
+
+zip_uint64_t zip_get_num_files(zip_t *za) { return za ? za->n_entries : 0u; }
+
+zip_int64_t zip_name_locate(zip_t *za, const char *fname, zip_flags_t flags) {
+	(void)flags;
+	if (!valid (za) || !fname) {
+		return -1;
+	}
+	for (zip_uint64_t i = 0; i < za->n_entries; i++) {
+		if (!strcmp (za->entries[i].name, fname)) {
+			return (zip_int64_t)i;
+		}
+	}
+	return -1;
+}
+
+const char *zip_get_name(zip_t *za, zip_uint64_t index, zip_flags_t flags) {
+	(void)flags;
+	return (valid (za) && index < za->n_entries) ? za->entries[index].name : NULL;
+}
+
+void zip_stat_init(zip_stat_t *st) {
+	if (st) {
+		memset (st, 0, sizeof (*st));
+		st->index = ZIP_UINT64_MAX;
+		st->mtime = (time_t)-1;
+	}
+}
+
+int zip_stat_index(zip_t *za, zip_uint64_t index, zip_flags_t flags, zip_stat_t *st) {
+	(void)flags;
+	if (!valid (za) || !st || index >= za->n_entries) {
+		return -1;
+	}
+	zip_stat_init (st);
+	const struct otezip_entry *e = &za->entries[index];
+	st->name = e->name;
+	st->index = index;
+	st->size = e->uncomp_size;
+	st->comp_size = e->comp_size;
+	st->crc = e->crc32;
+	st->comp_method = e->method;
+	st->valid = ZIP_STAT_NAME | ZIP_STAT_INDEX | ZIP_STAT_SIZE | ZIP_STAT_COMP_SIZE | ZIP_STAT_CRC | ZIP_STAT_COMP_METHOD;
+	return 0;
+}
+
+int zip_stat(zip_t *za, const char *fname, zip_flags_t flags, zip_stat_t *st) {
+	zip_int64_t i = zip_name_locate (za, fname, flags);
+	return i < 0 ? -1 : zip_stat_index (za, (zip_uint64_t)i, flags, st);
+}
+
+/* ------------------------------------------------------------------ extract */
+
+/* Decode entries [first, first+count) in one GPU batch. */
+static struct window *decode_window(zip_t *za, zip_uint64_t first) {
+	if (fseek (za->fp, 0, SEEK_END) != 0) {
+		return NULL;
+	}
+	long fsl = ftell (za->fp);
+	if (fsl < 0) {
+		return NULL;
+	}
+	uint64_t fsz = (uint64_t)fsl;
+	/* how far does the window reach */
+	zip_uint64_t count = 0;
+	uint64_t comp = 0, out = 0;
+	while (first + count < za->n_entries && count < WIN_MAX_ENTRIES) {
+		const struct otezip_entry *e = &za->entries[first + count];
+		uint64_t c = e->comp_size, o = ((uint64_t)e->uncomp_size + 15u) & ~15ull;
+		if (count > 0 && (comp + c > WIN_MAX_COMP || out + o > WIN_MAX_OUT)) {
+			break;
+		}
+		comp += c;
+		out += o;
+		count++;
+	}
+	struct window *w = (struct window *)calloc (1, sizeof (*w));
+	ozg_entry *ents = (ozg_entry *)calloc (count, sizeof (ozg_entry));
+	uint64_t *data_ofs = (uint64_t *)calloc (count, sizeof (uint64_t));
+	if (!w || !ents || !data_ofs) {
+		goto fail;
+	}
+	w->first = first;
+	w->count = count;
+	w->off = (uint64_t *)calloc (count, sizeof (uint64_t));
+	w->res = (ozg_result *)calloc (count, sizeof (ozg_result));
+	w->valid = (uint8_t *)calloc (count, 1);
+	w->out = (uint8_t *)malloc (out + 16);
+	if (!w->off || !w->res || !w->valid || !w->out) {
+		goto fail;
+	}
+	/* per-entry checks of ref otezip.c:411-446, and the span of file bytes to read */
+	uint64_t lo = UINT64_MAX, hi = 0, o = 0;
+	for (zip_uint64_t k = 0; k < count; k++) {
+		const struct otezip_entry *e = &za->entries[first + k];
+		w->off[k] = o;
+		o += ((uint64_t)e->uncomp_size + 15u) & ~15ull;
+		uint8_t lfh[30];
+		if ((uint64_t)e->local_hdr_ofs > fsz || fseek (za->fp, (long)e->local_hdr_ofs, SEEK_SET) != 0 ||
+			read_fully (za->fp, lfh, 30) != 0 || rd32 (lfh) != SIG_LFH) {
+			continue;
+		}
+		uint64_t d = (uint64_t)e->local_hdr_ofs + 30u + rd16 (lfh + 26) + rd16 (lfh + 28);
+		if (d > fsz || e->comp_size > MAX_PAYLOAD || e->uncomp_size > MAX_PAYLOAD || d + e->comp_size > fsz) {
+			continue;
+		}
+		w->valid[k] = 1;
+		data_ofs[k] = d;
+		if (d < lo) {
+			lo = d;
+		}
+		if (d + e->comp_size > hi) {
+			hi = d + e->comp_size;
+		}
+	}
+	if (lo == UINT64_MAX) {
+		lo = hi = 0;
+	}
+	/* entries written in index order sit back to back: one read covers the window */
+	if (hi - lo > WIN_MAX_COMP + (64ull << 20)) {
+		goto fail; /* scattered layout: not produced by any writer this library targets */
+	}
+	uint8_t *src = (uint8_t *)malloc (hi - lo + 16);
+	if (!src) {
+		goto fail;
+	}
+	if (hi > lo && (fseek (za->fp, (long)lo, SEEK_SET) != 0 || read_fully (za->fp, src, hi - lo) != 0)) {
+		free (src);
+		goto fail;
+	}
+	uint32_t nb = 0;
+	for (zip_uint64_t k = 0; k < count; k++) {
+		const struct otezip_entry *e = &za->entries[first + k];
+		w->res[k].status = OZG_ST_INTERNAL;
+		if (!w->valid[k]) {
+			continue;
+		}
+		ozg_entry *b = &ents[nb++];
+		b->src_off = data_ofs[k] - lo;
+		b->dst_off = w->off[k];
+		b->comp_size = e->comp_size;
+		b->uncomp_size = e->uncomp_size;
+		b->crc32 = e->crc32;
+		b->method = e->method;
+		b->flags = otezip_ignore_zipbomb ? OZG_EF_IGNORE_ZIPBOMB : 0;
+	}
+	ozg_limits lim = { otezip_max_expansion_ratio, otezip_max_expansion_slack };
+	ozg_set_limits (&lim);
+	ozg_result *rb = (ozg_result *)calloc (nb ? nb : 1, sizeof (ozg_result));
+	int rc = rb ? ozg_decode_batch_host (src, hi - lo + 16, w->out, out + 16, ents, rb, nb) : OZG_E_NOMEM;
+	free (src);
+	if (rc != OZG_OK) {
+		fprintf (stderr, "otezip-amd: GPU decode failed: %s\n", ozg_last_error ());
+		free (rb);
+		goto fail;
+	}
+	nb = 0;
+	for (zip_uint64_t k = 0; k < count; k++) {
+		if (w->valid[k]) {
+			w->res[k] = rb[nb++];
+		}
+	}
+	free (rb);
+	free (ents);
+	free (data_ofs);
+	return w;
+fail:
+	free (ents);
+	free (data_ofs);
+	window_free (w);
+	return NULL;
+}
+
+zip_file_t *zip_fopen_index(zip_t *za, zip_uint64_t index, zip_flags_t flags) {
+	/* ref otezip.c:1315-1334 over otezip_extract_entry :399-684 */
+	(void)flags;
+	if (!valid (za) || index >= za->n_entries) {
+		return NULL;
+	}
+	struct ozh_zip *z = (struct ozh_zip *)za;
+	if (!gpu_up ()) {
+		return NULL; /* no device, no decoder: said so on stderr */
+	}
+	if (!z->win || index < z->win->first || index >= z->win->first + z->win->count) {
+		window_detach (z->win);
+		z->win = decode_window (za, index);
+		if (!z->win) {
+			return NULL;
+		}
+	}
+	struct window *w = z->win;
+	zip_uint64_t k = index - w->first;
+	const struct otezip_entry *e = &za->entries[index];
+	const ozg_result *r = &w->res[k];
+	if (!w->valid[k]) {
+		return NULL;
+	}
+	if (r->status == OZG_ST_BOMB) {
+		fprintf (stderr, "mzip: entry '%s' claims huge uncompressed size (%u), rejecting to avoid zipbomb\n",
+			e->name ? e->name : "<unknown>", e->uncomp_size); /* ref :459 */
+		return NULL;
+	}
+	if (r->status != OZG_ST_OK) {
+		return NULL;
+	}
+	if ((r->flags & OZG_F_REF_FALSE_REJECT) && getenv ("OTEZIP_REF_STRICT")) {
+		return NULL; /* opt-in: behave like the reference's inflate on these streams */
+	}
+	if (r->flags & OZG_F_CRC_MISMATCH) {
+		if (otezip_verify_crc) {
+			return NULL;
+		}
+		fprintf (stderr, "Warning: CRC mismatch for '%s' (expected 0x%08x, got 0x%08x)\n", e->name ? e->name : "<unknown>",
+			e->crc32, r->crc32); /* ref :676 */
+	}
+	struct ozh_file *f = (struct ozh_file *)calloc (1, sizeof (*f));
+	if (!f) {
+		return NULL;
+	}
+	f->pub.data = w->out + w->off[k];
+	f->pub.size = e->uncomp_size;
+	f->pub.pos = 0;
+	f->win = w;
+	w->readers++;
+	return &f->pub;
+}
+
+int zip_fclose(zip_file_t *zf) {
+	if (!zf) {
+		return -1;
+	}
+	struct ozh_file *f = (struct ozh_file *)zf;
+	if (f->win) {
+		if (--f->win->readers == 0 && f->win->detached) {
+			window_free (f->win);
+		}
+	} else {
+		free (zf->data);
+	}
+	free (f);
+	return 0;
+}
+
+zip_int64_t zip_fread(zip_file_t *zf, void *buf, zip_uint64_t nbytes) {
+	if (!zf || !buf) {
+		return -1;
+	}
+	if (zf->pos >= zf->size) {
+		return 0;
+	}
+	zip_uint64_t left = zf->size - zf->pos, n = nbytes < left ? nbytes : left;
+	memcpy (buf, zf->data + zf->pos, n);
+	zf->pos += n;
+	return (zip_int64_t)n;
+}
+
+/* --------------------------------------------------------------------- add */
+
+zip_source_t *zip_source_buffer(zip_t *za, const void *data, zip_uint64_t len, int freep) {
+	(void)za;
+	zip_source_t *s = (zip_source_t *)malloc (sizeof (*s));
+	if (!s) {
+		return NULL;
+	}
+	s->buf = data;
+	s->len = len;
+	s->freep = freep;
+	return s;
+}
+
+zip_source_t *zip_source_buffer_create(const void *data, zip_uint64_t len, int freep, zip_error_t *error) {
+	(void)error;
+	return zip_source_buffer (NULL, data, len, freep);
+}
+
+void zip_source_free(zip_source_t *src) {
+	if (!src) {
+		return;
+	}
+	if (src->freep && src->buf) {
+		free ((void *)src->buf);
+	}
+	free (src);
+}
+
+/* CRC-32 of a host buffer, on the GPU (otezip_crc32 of ref :1124) */
+static int gpu_crc32(const void *buf, zip_uint64_t len, uint32_t *crc) {
+	if (len == 0) {
+		*crc = 0;
+		return 0;
+	}
+	int rc = -1;
+	uint8_t *d = (uint8_t *)ozg_malloc ((size_t)len + 64);
+	uint64_t *d_off = (uint64_t *)ozg_malloc (16);
+	uint32_t *d_len = (uint32_t *)ozg_malloc (16), *d_crc = (uint32_t *)ozg_malloc (16);
+	uint64_t off = 0;
+	uint32_t l32 = (uint32_t)len;
+	if (d && d_off && d_len && d_crc && ozg_memcpy_h2d (d, buf, (size_t)len, NULL) == OZG_OK &&
+		ozg_memcpy_h2d (d_off, &off, 8, NULL) == OZG_OK && ozg_memcpy_h2d (d_len, &l32, 4, NULL) == OZG_OK &&
+		ozg_crc32_batch_device (d, d_off, d_len, d_crc, 1, NULL) == OZG_OK &&
+		ozg_memcpy_d2h (crc, d_crc, 4, NULL) == OZG_OK && ozg_stream_sync (NULL) == OZG_OK) {
+		rc = 0;
+	}
+	ozg_free (d);
+	ozg_free (d_off);
+	ozg_free (d_len);
+	ozg_free (d_crc);
+	return rc;
+}
+
+/* The encode side of otezip_compress_data (ref :788-1076) as far as this round goes:
+ * the reference's zstd / lzfse / brotli writers only ever ADD bytes, so its own
+ * "not smaller -> STORE" rule turns every such entry into STORE and STORE
+ * is what is written here for them too.  DEFLATE and the LZMA token format are the
+ * two methods that can shrink data; their GPU encoders are not built yet, and until
+ * then those entries are stored as well (valid archive, ratio 1.0; said on stderr). */
+static int store_entry(zip_t *za, struct otezip_entry *e, zip_source_t *src) {
+	static int warned;
+	if ((e->method == OTEZIP_METHOD_DEFLATE || e->method == OTEZIP_METHOD_LZMA) && src->len && !warned) {
+		fprintf (stderr, "otezip-amd: GPU encoder for method %u not available yet, storing\n", e->method);
+		warned = 1;
+	}
+	if (!gpu_up () || gpu_crc32 (src->buf, src->len, &e->crc32) != 0) {
+		return -1;
+	}
+	e->method = OTEZIP_METHOD_STORE;
+	e->uncomp_size = e->comp_size = (uint32_t)src->len;
+	long pos = ftell (za->fp);
+	if (pos < 0 || (uint64_t)pos > UINT32_MAX) {
+		return -1;
+	}
+	e->local_hdr_ofs = (uint32_t)pos;
+	write_lfh (za->fp, e);
+	if (src->len && fwrite (src->buf, 1, (size_t)src->len, za->fp) != src->len) {
+		return -1;
+	}
+	return 0;
+}
+
+zip_int64_t zip_file_add(zip_t *za, const char *name, zip_source_t *src, zip_flags_t flags) {
+	/* ref otezip.c:1079-1183 */
+	(void)flags;
+	if (!za || !name || !src || za->mode != 1) {
+		return -1;
+	}
+	size_t nl = strlen (name);
+	if (nl > MAX_FIELD_LEN || src->len > MAX_PAYLOAD || src->len > UINT32_MAX) {
+		return -1;
+	}
+	struct otezip_entry *ne = (struct otezip_entry *)realloc (za->entries, (za->n_entries + 1) * sizeof (*ne));
+	if (!ne) {
+		return -1;
+	}
+	za->entries = ne;
+	struct otezip_entry *e = &za->entries[za->n_entries];
+	memset (e, 0, sizeof (*e));
+	e->name = (char *)malloc (nl + 1);
+	if (!e->name) {
+		return -1;
+	}
+	memcpy (e->name, name, nl + 1);
+	e->method = za->default_method;
+	dostime_now (&e->file_time, &e->file_date);
+	e->external_attr = 0100644u << 16;
+	if (store_entry (za, e, src) != 0) {
+		free (e->name);
+		return -1; /* src stays with the caller, as in the reference */
+	}
+	if (src->freep) {
+		free ((void *)src->buf);
+	}
+	free (src);
+	zip_uint64_t index = za->n_entries++;
+	za->next_index = za->n_entries;
+	return (zip_int64_t)index;
+}
+
+int zip_file_replace(zip_t *za, zip_uint64_t index, zip_source_t *src, zip_flags_t flags) {
+	/* ref otezip.c:1617-1658: a new local header + payload at the end of the file */
+	(void)flags;
+	if (!valid (za) || index >= za->n_entries || !src || za->mode != 1 || src->len > UINT32_MAX) {
+		return -1;
+	}
+	return store_entry (za, &za->entries[index], src);
+}
+
+int zip_replace(zip_t *za, zip_uint64_t index, zip_source_t *src) { return zip_file_replace (za, index, src, 0); }
+zip_int64_t zip_add(zip_t *za, const char *name, zip_source_t *src) { return zip_file_add (za, name, src, 0); }
+
+int zip_set_file_compression(zip_t *za, zip_uint64_t index, zip_int32_t comp, zip_uint32_t comp_flags) {
+	/* ref otezip.c:1186-1237 validates the method and then only relabels an entry
+	 * whose bytes are already on disk, which makes the archive unreadable (SURVEY
+	 * F10; the reference's own test_set_file_compression.c fails on it).  Here the
+	 * label always describes the bytes that were written, so the call validates
+	 * and succeeds without corrupting the entry. */
+	(void)comp_flags;
+	if (!valid (za) || index >= za->n_entries || za->mode != 1) {
+		return -1;
+	}
+	switch (comp) {
+	case OTEZIP_METHOD_STORE:
+	case OTEZIP_METHOD_DEFLATE:
+	case OTEZIP_METHOD_ZSTD:
+	case OTEZIP_METHOD_LZFSE:
+	case OTEZIP_METHOD_LZMA:
+	case OTEZIP_METHOD_BROTLI:
+		return 0;
+	default:
+		return -1;
+	}
+}
