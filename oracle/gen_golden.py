@@ -93,7 +93,9 @@ def main():
     add("deflate_crc_mismatch", 8, c, 3000, zlib.crc32(d) ^ 1, note="readable; reference only warns")
     add("deflate_empty_input", 8, b"", 0, 0)
     bomb = b"\0" * 1_100_000
-    add("deflate_zipbomb_guard", 8, raw(bomb), len(bomb), zlib.crc32(bomb), note="uncomp > comp*1000 + 1 MiB")
+    add("deflate_ratio_1000_inside_slack", 8, raw(bomb), len(bomb), zlib.crc32(bomb))
+    add("deflate_zipbomb_guard", 8, raw(bomb)[:20], 5_000_000, 0, note="claims uncomp > comp*1000 + 1 MiB: rejected unread")
+    add("deflate_zipbomb_guard_ignored", 8, raw(bomb)[:20], 5_000_000, 0, flags=1, note="guard off: truncated stream")
     # STORE and the private framings, 4 KiB payloads
     p = text(r, 4096)
     add("store_4k", 0, p, 4096, zlib.crc32(p))

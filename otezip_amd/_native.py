@@ -78,6 +78,13 @@ def lib():
         if not os.path.exists(p):
             raise NativeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950). There is no CPU fallback." % p)
+        # One HIP runtime per process: torch ships its own libamdhip64.so.7 and looks it up by
+        # file name, so it has to be loaded BEFORE this library's DT_NEEDED entry is resolved
+        # (then both share torch's copy).  Plain C hosts never load torch and use /opt/rocm.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(p)
         for name, (res, args) in ABI.items():
             f = getattr(L, name)

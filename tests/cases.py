@@ -75,8 +75,10 @@ def deflate_edge(seed=3):
     out.append((8, b"", 10, 0, 0))
     big = b"\0" * 1_200_000
     cb = raw_deflate(big)
-    out.append((8, cb, len(big), crc(big), 0))                       # > 1000x + 1 MiB: rejected
-    out.append((8, cb, len(big), crc(big), 1))                       # guard overridden
+    out.append((8, cb, len(big), crc(big), 0))                       # ratio ~1000 but inside the 1 MiB slack: fine
+    out.append((8, cb[:20], 5_000_000, 0, 0))                        # claims > comp*1000 + 1 MiB: zip-bomb guard
+    out.append((8, cb[:20], 5_000_000, 0, 1))                        # guard overridden: now it is just truncated
+    out.append((0, b"x" * 20, 5_000_000, 0, 0))                      # the guard comes before the method switch
     return out
 
 
