@@ -114,15 +114,13 @@ def main():
     ap.add_argument("--cache-dir", default=os.environ.get("OTEZIP_BENCH_CACHE", "/tmp/otezip_amd_cache"))
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from otezip_amd import dist as D
+    rank, local_rank, world = D.env_world()
     if world != args.gpus:
         log("[bench] WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
 
     import numpy as np
     import torch
-    import torch.distributed as dist
     import otezip_amd as oz
     from otezip_amd import _native as N
 
@@ -132,9 +130,7 @@ def main():
         raise SystemExit("bench.py needs a GPU: otezip-amd has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    D.init("nccl", dev)
     oz.init(local_rank)
     L = oz.lib()
 
@@ -158,8 +154,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    D.barrier()
     torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
@@ -168,15 +163,10 @@ def main():
         step()
         b.record(stream)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    D.barrier()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = D.reduce_max(time.perf_counter() - t0, dev)
     kernel_ms = [a.elapsed_time(b) for a, b in evs]
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     # every entry must have decoded and must match the directory CRC
     res = np.frombuffer(d_res.cpu().numpy().tobytes(), dtype=np.int32).reshape(n, 4)
@@ -195,11 +185,8 @@ def main():
         raise SystemExit("[bench] INVALID RUN: %d entries failed, %d CRC mismatches, %d byte mismatches" %
                          (bad, crc_bad, mism))
 
-    ok = torch.tensor([1.0], device=dev)
-    if world > 1:
-        dist.all_reduce(ok)
+    total_out = D.reduce_sum(out_bytes, dev)  # whole job: every rank's shard
     if rank == 0:
-        total_out = out_bytes * world  # every rank decodes a shard of the same shape
         value = total_out * args.steps / elapsed / 2**30
         kavg = sum(kernel_ms) / len(kernel_ms) * 1e-3
         algo = comp_bytes + out_bytes
@@ -226,8 +213,7 @@ def main():
                 line["cpu_baseline"] = {"value": None, "unit": "GiB/s", "cores": 0, "kind": "reference",
                                         "sample": "failed: %r" % (ex,)}
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    D.finish()
     oz.shutdown()
 
 
