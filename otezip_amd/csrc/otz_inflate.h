@@ -35,16 +35,16 @@
 #include "../../include/otezip_gpu.h"
 
 #ifndef OTZ_NT
-#define OTZ_NT 256u            // work-items per workgroup (4 wavefronts)
+#define OTZ_NT 512u            // work-items per workgroup (8 wavefronts)
 #endif
-#define OTZ_RING 65536u
-#define OTZ_RING_MASK 65535u
+#define OTZ_RING 57344u          // 56 KiB: 32 KiB LZ77 window + one round of output (OTZ_RMAX); not a power of two
+#define OTZ_RIDX(p) ((p) % OTZ_RING) // absolute output position -> ring index (constant modulo: mul_hi + sub)
 #ifndef OTZ_S_BITS
-#define OTZ_S_BITS 128u         // speculative subsequence per lane per round (at most 128)
+#define OTZ_S_BITS 128u         // speculative subsequence per lane per round (at most 256)
 #endif
-#define OTZ_TOK_CAP 32u         // tokens per pass-A path (bounds lane 0's output)
-#define OTZ_RMAX 16384u         // output bytes per round (size of the final bitmap)
-#define OTZ_STAGE_BYTES 4608u   // OTZ_NT * OTZ_S_BITS / 8 = 4096 B + skew + lookahead; also holds the CRC tables
+#define OTZ_TOK_CAP 64u         // tokens per pass-A path (bounds lane 0's output: 64 * 258 < OTZ_RMAX)
+#define OTZ_RMAX 24576u         // output bytes per round (size of the bitmaps); OTZ_RING - OTZ_RMAX = the 32 KiB window
+#define OTZ_STAGE_BYTES 8704u   // OTZ_NT * OTZ_S_BITS / 8 = 8192 B + skew + lookahead; also holds the CRC tables
 #define OTZ_STAGE_WORDS (OTZ_STAGE_BYTES / 4)
 #define OTZ_LIT_ROOT 9          // two-level tables: root + sub-tables for the longer codes
 #define OTZ_DIST_ROOT 8
@@ -392,12 +392,12 @@ OTZ_DEV void otz_flush(otz_inflate_lds &L, const otz_job &J, u32 &flushed, u32 u
 	u32 nch = n >> 4, tail = n & 15u;
 	u32 tid = otz_tid ();
 	for (u32 c = tid; c < nch; c += OTZ_NT) {
-		u32 a = (flushed + 16u * c) & OTZ_RING_MASK;
+		u32 a = OTZ_RIDX (flushed + 16u * c);
 		otz_u4 v = *reinterpret_cast<const otz_u4 *> (&L.ring[a]);
 		otz_st16_aligned (J.out + flushed + 16u * c, v);
 	}
 	if (tid < tail) {
-		J.out[flushed + 16u * nch + tid] = L.ring[(flushed + 16u * nch + tid) & OTZ_RING_MASK];
+		J.out[flushed + 16u * nch + tid] = L.ring[OTZ_RIDX (flushed + 16u * nch + tid)];
 	}
 	otz_sync ();
 	// contiguous run of chunks per lane; an odd run length keeps the 16-byte LDS
@@ -409,7 +409,7 @@ OTZ_DEV void otz_flush(otz_inflate_lds &L, const otz_job &J, u32 &flushed, u32 u
 	}
 	u32 r = 0;
 	for (u32 c = c0; c < c1; c++) {
-		u32 a = (flushed + 16u * c) & OTZ_RING_MASK;
+		u32 a = OTZ_RIDX (flushed + 16u * c);
 		otz_u4 v = *reinterpret_cast<const otz_u4 *> (&L.ring[a]);
 		r = otz_crc_chunk16 (r, v, L.crc_t4);
 	}
@@ -422,7 +422,7 @@ OTZ_DEV void otz_flush(otz_inflate_lds &L, const otz_job &J, u32 &flushed, u32 u
 	if (tail && tid == OTZ_NT - 1u) {
 		u32 rt = 0;
 		for (u32 k = 0; k < tail; k++) {
-			rt = otz_crc_byte (rt, L.ring[(flushed + 16u * nch + k) & OTZ_RING_MASK], L.crc_t4);
+			rt = otz_crc_byte (rt, L.ring[OTZ_RIDX (flushed + 16u * nch + k)], L.crc_t4);
 		}
 		r ^= rt;
 	}
@@ -750,7 +750,7 @@ struct otz_path {
 #define OTZ_MODE_PREFIX 2 // from the speculative start up to `stop`
 
 template <int MODE>
-OTZ_DEV otz_path otz_walk(const otz_inflate_lds &L, const otz_dec &D, u32 start, u32 s, u32 e, u32 limit_bits, u32 stop, u32 (&vis)[4]) {
+OTZ_DEV otz_path otz_walk(const otz_inflate_lds &L, const otz_dec &D, u32 start, u32 s, u32 e, u32 limit_bits, u32 stop, u32 (&vis)[8]) {
 	otz_path P;
 	P.bytes = 0;
 	P.syncq = ~0u;
@@ -776,6 +776,10 @@ OTZ_DEV otz_path otz_walk(const otz_inflate_lds &L, const otz_dec &D, u32 start,
 				vis[1] |= ck == 1 ? cw : 0u;
 				vis[2] |= ck == 2 ? cw : 0u;
 				vis[3] |= ck == 3 ? cw : 0u;
+				vis[4] |= ck == 4 ? cw : 0u;
+				vis[5] |= ck == 5 ? cw : 0u;
+				vis[6] |= ck == 6 ? cw : 0u;
+				vis[7] |= ck == 7 ? cw : 0u;
 				cw = 0;
 				ck = k;
 			}
@@ -783,7 +787,9 @@ OTZ_DEV otz_path otz_walk(const otz_inflate_lds &L, const otz_dec &D, u32 start,
 		}
 		if (MODE == OTZ_MODE_B) {
 			u32 k = rel >> 5;
-			u32 w = k == 0 ? vis[0] : k == 1 ? vis[1] : k == 2 ? vis[2] : vis[3];
+			u32 wa = k & 2u ? (k & 1u ? vis[3] : vis[2]) : (k & 1u ? vis[1] : vis[0]);
+			u32 wb = k & 2u ? (k & 1u ? vis[7] : vis[6]) : (k & 1u ? vis[5] : vis[4]);
+			u32 w = k & 4u ? wb : wa;
 			if ((w >> (rel & 31u)) & 1u) {
 				P.syncq = pos;
 				break;
@@ -811,6 +817,10 @@ OTZ_DEV otz_path otz_walk(const otz_inflate_lds &L, const otz_dec &D, u32 start,
 		vis[1] |= ck == 1 ? cw : 0u;
 		vis[2] |= ck == 2 ? cw : 0u;
 		vis[3] |= ck == 3 ? cw : 0u;
+		vis[4] |= ck == 4 ? cw : 0u;
+		vis[5] |= ck == 5 ? cw : 0u;
+		vis[6] |= ck == 6 ? cw : 0u;
+		vis[7] |= ck == 7 ? cw : 0u;
 	}
 	return P;
 }
@@ -871,7 +881,7 @@ OTZ_DEV void otz_place(otz_inflate_lds &L, const otz_dec &D, bool active, u32 st
 		u32 tpos = pos;
 		pos += t.nbits;
 		if (t.kind == OTZ_K_LIT) {
-			L.ring[o & OTZ_RING_MASK] = (u8)t.val;
+			L.ring[OTZ_RIDX (o)] = (u8)t.val;
 			o++;
 			continue;
 		}
@@ -896,9 +906,9 @@ OTZ_DEV void otz_place(otz_inflate_lds &L, const otz_dec &D, bool active, u32 st
 			return;
 		}
 		u32 d = (t.dist - 1u) | ((t.val - 3u) << 15);
-		L.ring[o & OTZ_RING_MASK] = (u8)d;
-		L.ring[(o + 1u) & OTZ_RING_MASK] = (u8) (d >> 8);
-		L.ring[(o + 2u) & OTZ_RING_MASK] = (u8) (d >> 16);
+		L.ring[OTZ_RIDX (o)] = (u8)d;
+		L.ring[OTZ_RIDX (o + 1u)] = (u8) (d >> 8);
+		L.ring[OTZ_RIDX (o + 2u)] = (u8) (d >> 16);
 		u32 rel = o - round_base;
 		otz_lds_or (&L.mstart[rel >> 5], 1u << (rel & 31u));
 		o += t.val;
@@ -941,8 +951,8 @@ OTZ_DEV void otz_resolve(otz_inflate_lds &L, u32 round_base, u32 round_bytes) {
 				u32 b = otz_ctz (cand);
 				cand &= cand - 1u;
 				u32 at = round_base + 32u * w + b;
-				u32 d = (u32)L.ring[at & OTZ_RING_MASK] | ((u32)L.ring[(at + 1u) & OTZ_RING_MASK] << 8) |
-					((u32)L.ring[(at + 2u) & OTZ_RING_MASK] << 16);
+				u32 d = (u32)L.ring[OTZ_RIDX (at)] | ((u32)L.ring[OTZ_RIDX (at + 1u)] << 8) |
+					((u32)L.ring[OTZ_RIDX (at + 2u)] << 16);
 				u32 dist = (d & 0x7FFFu) + 1u, len = (d >> 15) + 3u;
 				u32 s0 = at - dist;
 				u32 e0 = s0 + (len < dist ? len : dist);
@@ -976,18 +986,18 @@ OTZ_DEV void otz_resolve(otz_inflate_lds &L, u32 round_base, u32 round_bytes) {
 #pragma unroll
 				for (u32 k = 0; k < 8; k++) {
 					if (k < n) {
-						tmp[k] = L.ring[(o - pdist + k) & OTZ_RING_MASK];
+						tmp[k] = L.ring[OTZ_RIDX (o - pdist + k)];
 					}
 				}
 #pragma unroll
 				for (u32 k = 0; k < 8; k++) {
 					if (k < n) {
-						L.ring[(o + k) & OTZ_RING_MASK] = tmp[k];
+						L.ring[OTZ_RIDX (o + k)] = tmp[k];
 					}
 				}
 			} else {
 				for (u32 k = 0; k < n; k++) {
-					L.ring[(o + k) & OTZ_RING_MASK] = L.ring[(o + k - pdist) & OTZ_RING_MASK];
+					L.ring[OTZ_RIDX (o + k)] = L.ring[OTZ_RIDX (o + k - pdist)];
 				}
 			}
 			otz_mark_final (L, o - round_base, o + n - round_base);
@@ -1008,12 +1018,12 @@ OTZ_DEV void otz_resolve(otz_inflate_lds &L, u32 round_base, u32 round_bytes) {
 // Cooperative copy of n input bytes (entry offset src_byte) to the ring at opos.
 OTZ_DEV void otz_copy_in(otz_inflate_lds &L, const otz_job &J, u32 src_byte, u32 opos, u32 n) {
 	for (u32 i = otz_tid (); i < n; i += OTZ_NT) {
-		L.ring[(opos + i) & OTZ_RING_MASK] = J.in[src_byte + i];
+		L.ring[OTZ_RIDX (opos + i)] = J.in[src_byte + i];
 	}
 }
 OTZ_DEV void otz_fill_zero(otz_inflate_lds &L, u32 opos, u32 n) {
 	for (u32 i = otz_tid (); i < n; i += OTZ_NT) {
-		L.ring[(opos + i) & OTZ_RING_MASK] = 0;
+		L.ring[OTZ_RIDX (opos + i)] = 0;
 	}
 }
 
@@ -1191,7 +1201,7 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 			OTZ_COUNT (L, J, OTZ_P_ROUNDS, 1);
 			// pass A
 			const u32 s = p0 + tid * OTZ_S_BITS, e = s + OTZ_S_BITS;
-			u32 vis[4] = { 0, 0, 0, 0 };
+			u32 vis[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 			otz_path A = otz_walk<OTZ_MODE_A> (L, D, s, s, e, limit_bits, 0, vis);
 			L.exits[tid] = A.exit;
 			otz_sync ();
@@ -1247,7 +1257,7 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 				} else {
 					u32 pre = 0;
 					if (q != s) {
-						u32 dummy[4] = { 0, 0, 0, 0 };
+						u32 dummy[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 						pre = otz_walk<OTZ_MODE_PREFIX> (L, D, s, s, e, limit_bits, q, dummy).bytes;
 					}
 					bytes = wbytes + A.bytes - pre;
