@@ -15,6 +15,7 @@
  *   ozg_decode_batch_device   device-resident src/dst/tables, async on a stream
  *   ozg_decode_batch_device_ex  same, with a method-mix hint
  *   ozg_decode_batch_host     host buffers; stages over PCIe and waits
+ *   ozg_encode_batch_device / _host   the encode side, same conventions
  *   ozg_crc32_batch_device    otezip_crc32 (ref src/lib/crc32.inc.c:40-47) x N
  *   ozg_malloc / ozg_free / ozg_memcpy_* / ozg_stream_sync   so that host C
  *                             code needs no HIP headers
@@ -115,6 +116,38 @@ int ozg_decode_batch_device_ex(const void *d_src, uint64_t src_len, void *d_dst,
  * batch, copies dst and results back, and waits. */
 int ozg_decode_batch_host(const void *src, uint64_t src_len, void *dst, uint64_t dst_len,
 	const ozg_entry *entries, ozg_result *results, uint32_t n);
+
+/* ---- encode: otezip_compress_data (ref src/lib/otezip.c:788-1076) + the CRC of zip_file_add (:1124) ---- */
+
+/* One buffer to compress. 32 bytes. */
+typedef struct ozg_enc_entry {
+	uint64_t src_off;  /* input: src + src_off, any alignment */
+	uint64_t dst_off;  /* output: dst + dst_off, MUST be a multiple of 16 */
+	uint32_t src_size;
+	uint32_t dst_cap;  /* >= ozg_compress_bound(method, src_size) */
+	uint16_t method;   /* requested method (what za->default_method holds) */
+	uint16_t level;    /* ignored: the reference always runs its default level (ref :826) */
+	uint32_t reserved;
+} ozg_enc_entry;
+
+/* 16 bytes */
+typedef struct ozg_enc_result {
+	int32_t status;     /* OZG_ST_OK, or OZG_ST_INTERNAL on a bad descriptor */
+	uint32_t comp_size; /* bytes written at dst + dst_off */
+	uint32_t crc32;     /* CRC-32 of the INPUT buffer */
+	uint16_t method;    /* method actually written: the requested one, or STORE after the
+	                       reference's "not smaller -> STORE" rule (ref :846-850 etc.) */
+	uint16_t flags;
+} ozg_enc_result;
+
+/* output space the reference allocates per method (ref :819, :860, :931, :975, :1019),
+ * never less than src_size so that the STORE fallback fits */
+uint64_t ozg_compress_bound(uint16_t method, uint64_t src_size);
+
+int ozg_encode_batch_device(const void *d_src, uint64_t src_len, void *d_dst, uint64_t dst_len,
+	const ozg_enc_entry *d_entries, ozg_enc_result *d_results, uint32_t n, void *stream);
+int ozg_encode_batch_host(const void *src, uint64_t src_len, void *dst, uint64_t dst_len,
+	const ozg_enc_entry *entries, ozg_enc_result *results, uint32_t n);
 
 /* crc[i] = CRC-32 of d_buf[off[i] .. off[i]+len[i]) (all device pointers). */
 int ozg_crc32_batch_device(const void *d_buf, const uint64_t *d_off, const uint32_t *d_len, uint32_t *d_crc,

@@ -123,10 +123,19 @@ def main():
             note="reference stages at most 65536 bytes (F8)" if n == 65537 else "")
     add("method_unsupported", 12, p, 4096, zlib.crc32(p))
 
+    # reference DEFLATE encoder: only its output SIZE is meaningful (its bytes are invalid)
+    from otezip_amd import corpus
+    enc_sizes = []
+    for seed, size in [(0, 65536), (1, 65536), (2, 65536), (3, 65536), (7, 20000), (8, 3000), (9, 100)]:
+        d = corpus.gen_text(seed, size)
+        ret, outb = O.ref_codec_encode(8, d, len(d) + len(d) // 8 + 75)
+        assert ret == O.Z_STREAM_END
+        enc_sizes.append(dict(seed=seed, size=size, ref_deflate_size=len(outb), input_crc32=zlib.crc32(d) & 0xFFFFFFFF))
     out = os.path.join(os.path.dirname(HERE), "tests", "golden", "entries.json")
     with open(out, "w") as f:
         json.dump(dict(generator="oracle/gen_golden.py", reference="trufae/otezip @ /root/reference (2026-03-13)",
-                       empty_zip_hex="504b0506" + "00" * 18, entries=fx), f, indent=0)
+                       empty_zip_hex="504b0506" + "00" * 18, entries=fx,
+                       ref_deflate_sizes=enc_sizes), f, indent=0)
     print("wrote %s: %d fixtures, %d bytes" % (out, len(fx), os.path.getsize(out)))
 
 

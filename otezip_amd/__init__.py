@@ -14,6 +14,6 @@ from ._native import (  # noqa: F401
     METHOD_STORE, METHOD_DEFLATE, METHOD_LZMA, METHOD_ZSTD, METHOD_BROTLI, METHOD_LZFSE,
     BATCH_ONLY_DEFLATE, BATCH_NO_DEFLATE,
 )
-from .batch import Batch, decode_batch_host, make_entries  # noqa: F401
+from .batch import Batch, decode_batch_host, encode_batch_host, make_entries  # noqa: F401
 
 __version__ = "0.1.0"

@@ -25,6 +25,16 @@ class OzgResult(C.Structure):
     _fields_ = [("status", C.c_int32), ("total_out", C.c_uint32), ("crc32", C.c_uint32), ("flags", C.c_uint32)]
 
 
+class OzgEncEntry(C.Structure):
+    _fields_ = [("src_off", C.c_uint64), ("dst_off", C.c_uint64), ("src_size", C.c_uint32), ("dst_cap", C.c_uint32),
+                ("method", C.c_uint16), ("level", C.c_uint16), ("reserved", C.c_uint32)]
+
+
+class OzgEncResult(C.Structure):
+    _fields_ = [("status", C.c_int32), ("comp_size", C.c_uint32), ("crc32", C.c_uint32), ("method", C.c_uint16),
+                ("flags", C.c_uint16)]
+
+
 class OzgLimits(C.Structure):
     _fields_ = [("max_expansion_ratio", C.c_uint64), ("max_expansion_slack", C.c_uint64)]
 
@@ -56,6 +66,9 @@ ABI = {
     "ozg_decode_batch_device": (C.c_int, [_VP, _U64, _VP, _U64, _VP, _VP, _U32, _VP]),
     "ozg_decode_batch_device_ex": (C.c_int, [_VP, _U64, _VP, _U64, _VP, _VP, _U32, _VP, _U32]),
     "ozg_decode_batch_host": (C.c_int, [_VP, _U64, _VP, _U64, C.POINTER(OzgEntry), C.POINTER(OzgResult), _U32]),
+    "ozg_compress_bound": (C.c_uint64, [C.c_uint16, _U64]),
+    "ozg_encode_batch_device": (C.c_int, [_VP, _U64, _VP, _U64, _VP, _VP, _U32, _VP]),
+    "ozg_encode_batch_host": (C.c_int, [_VP, _U64, _VP, _U64, C.POINTER(OzgEncEntry), C.POINTER(OzgEncResult), _U32]),
     "ozg_crc32_batch_device": (C.c_int, [_VP, _VP, _VP, _VP, _U32, _VP]),
     "ozg_malloc": (_VP, [C.c_size_t]),
     "ozg_free": (None, [_VP]),

@@ -50,3 +50,33 @@ def decode_batch_host(src, items):
     res = (N.OzgResult * max(n, 1))()
     N.check(N.lib().ozg_decode_batch_host(src, len(src), dst, dst_len, ents, res, n), "ozg_decode_batch_host")
     return Batch(ents, res, dst.raw, n)
+
+
+def encode_batch_host(buffers, method=8):
+    """ozg_encode_batch_host over a list of bytes objects (what zip_file_add does per entry,
+    batched).  Returns [(method_written, payload_bytes, crc32_of_input)]."""
+    bufs = [bytes(b) for b in buffers]
+    n = len(bufs)
+    ents = (N.OzgEncEntry * max(n, 1))()
+    src = bytearray()
+    off = 0
+    L = N.lib()
+    for i, b in enumerate(bufs):
+        ents[i].src_off = len(src)
+        src += b
+        ents[i].src_size = len(b)
+        ents[i].method = method
+        cap = int(L.ozg_compress_bound(method, len(b)))
+        ents[i].dst_cap = cap
+        ents[i].dst_off = off
+        off += (cap + 15) & ~15
+    src += b"\0" * 16
+    dst = C.create_string_buffer(off + 16)
+    res = (N.OzgEncResult * max(n, 1))()
+    N.check(L.ozg_encode_batch_host(bytes(src), len(src), dst, off + 16, ents, res, n), "ozg_encode_batch_host")
+    out = []
+    for i in range(n):
+        if res[i].status != N.ST_OK:
+            raise N.NativeError("encode entry %d failed: %d" % (i, res[i].status))
+        out.append((res[i].method, dst.raw[ents[i].dst_off:ents[i].dst_off + res[i].comp_size], res[i].crc32))
+    return out

@@ -1,0 +1,279 @@
+// otz_deflate_enc.h -- raw DEFLATE encoder, one wavefront per buffer.  Replaces
+// deflateInit2(level 6, -15)/deflate(Z_FINISH)/deflateEnd as otezip_compress_data
+// drives them (ref src/lib/otezip.c:817-852, src/lib/deflate-enc.inc.c:199-525).
+//
+// This is a re-specification, not a mirror: the reference's encoder writes its
+// Huffman codes without the bit reversal RFC 1951 section 3.1.1 requires and
+// wraps its window position at 32 KiB, so nothing can decode its
+// output -- only its SIZE is a meaningful observable (parity rule 5).  What is
+// kept is its shape: one fixed-Huffman block, greedy LZ77 with a single hash
+// probe per position (ref :32-112, :333-513).  What is different: the output is
+// valid DEFLATE, and the stream ends with an EMPTY FINAL STORED BLOCK so that the
+// reference's own inflate, which rejects a final end-of-block code that starts at
+// bit 1 of the last byte, accepts every stream produced here.
+//
+// Layout: 16 KiB LDS ring of input (matches reach 14 848 bytes back), 4096-entry
+// hash head table, 2 KiB of staged output flushed with coalesced 16-byte stores.
+// The 64 lanes compare 64 candidate bytes per step (ballot + count-trailing-zeros
+// gives the match length) and insert the hashes of a whole match at once; token
+// selection itself is sequential per buffer -- throughput comes from the thousands
+// of buffers a batch holds.
+#pragma once
+
+#include "otz_simt.h"
+#include "../../include/otezip_gpu.h"
+
+#define OTZ_ENC_NT 64u
+#define OTZ_ENC_WIN 16384u
+#define OTZ_ENC_WMASK (OTZ_ENC_WIN - 1u)
+#define OTZ_ENC_MAXDIST 14848u // ring 16384 - (lookahead 322 + load chunk 1024 + slack)
+#define OTZ_ENC_HASH 4096u
+#define OTZ_ENC_OUT 2048u
+
+struct otz_enc_lds {
+	u8 win[OTZ_ENC_WIN];
+	u16 head[OTZ_ENC_HASH];
+	u32 out_w[OTZ_ENC_OUT / 4];
+};
+
+struct otz_enc_state {
+	u64 acc;        // pending output bits, LSB first
+	u32 nacc;
+	u32 stage_fill; // bytes staged in L.out_w
+	u32 out_pos;    // bytes already in global memory
+	u32 cap;
+	u8 *dst;
+	bool overflow;
+};
+
+OTZ_DEV void otz_enc_flush_stage(otz_enc_lds &L, otz_enc_state &S) {
+	otz_sync ();
+	u32 n = S.stage_fill;
+	if (S.out_pos + n > S.cap) {
+		S.overflow = true;
+		n = 0;
+	}
+	const u8 *src = reinterpret_cast<const u8 *> (L.out_w);
+	if ((n & 15u) == 0) {
+		for (u32 c = otz_tid (); c < (n >> 4); c += OTZ_ENC_NT) {
+			otz_st16_aligned (S.dst + S.out_pos + 16u * c, *reinterpret_cast<const otz_u4 *> (src + 16u * c));
+		}
+	} else {
+		for (u32 i = otz_tid (); i < n; i += OTZ_ENC_NT) {
+			S.dst[S.out_pos + i] = src[i];
+		}
+	}
+	S.out_pos += n;
+	S.stage_fill = 0;
+	otz_sync ();
+}
+
+// append nbits (<= 32) of v; every lane tracks the state, lane 0 stores
+OTZ_DEV void otz_enc_put(otz_enc_lds &L, otz_enc_state &S, u32 v, u32 nbits) {
+	S.acc |= (u64)v << S.nacc;
+	S.nacc += nbits;
+	if (S.nacc >= 32u) {
+		if (otz_tid () == 0) {
+			L.out_w[S.stage_fill >> 2] = (u32)S.acc;
+		}
+		S.acc >>= 32;
+		S.nacc -= 32u;
+		S.stage_fill += 4u;
+		if (S.stage_fill == OTZ_ENC_OUT) {
+			otz_enc_flush_stage (L, S);
+		}
+	}
+}
+
+// fixed literal/length code of RFC 1951 3.2.6, bit-reversed for LSB-first packing
+OTZ_DEV void otz_enc_put_litlen(otz_enc_lds &L, otz_enc_state &S, u32 sym) {
+	u32 code, n;
+	if (sym <= 143u) {
+		code = 0x30u + sym;
+		n = 8;
+	} else if (sym <= 255u) {
+		code = 0x190u + (sym - 144u);
+		n = 9;
+	} else if (sym <= 279u) {
+		code = sym - 256u;
+		n = 7;
+	} else {
+		code = 0xC0u + (sym - 280u);
+		n = 8;
+	}
+	otz_enc_put (L, S, otz_brev (code) >> (32u - n), n);
+}
+
+OTZ_DEV void otz_enc_put_match(otz_enc_lds &L, otz_enc_state &S, u32 len, u32 dist) {
+	if (len == 258u) {
+		otz_enc_put_litlen (L, S, 285u);
+	} else {
+		u32 l = len - 3u;
+		if (l < 8u) {
+			otz_enc_put_litlen (L, S, 257u + l);
+		} else {
+			u32 hb = 31u - (u32)__builtin_clz (l), xb = hb - 2u;
+			otz_enc_put_litlen (L, S, 257u + 4u * hb - 4u + ((l >> xb) & 3u));
+			otz_enc_put (L, S, l & ((1u << xb) - 1u), xb);
+		}
+	}
+	u32 d = dist - 1u;
+	if (d < 4u) {
+		otz_enc_put (L, S, otz_brev (d) >> 27, 5);
+	} else {
+		u32 hb = 31u - (u32)__builtin_clz (d), xb = hb - 1u;
+		u32 code = 2u * hb + ((d >> xb) & 1u);
+		otz_enc_put (L, S, otz_brev (code) >> 27, 5);
+		otz_enc_put (L, S, d & ((1u << xb) - 1u), xb);
+	}
+}
+
+OTZ_DEV u32 otz_enc_hash(u32 b0, u32 b1, u32 b2) {
+	return (((b0 | (b1 << 8) | (b2 << 16)) * 0x9E3779B1u) >> 20) & (OTZ_ENC_HASH - 1u);
+}
+
+// Encode src[0..n) into dst (capacity cap). All 64 work-items call together and all
+// get the compressed size, or ~0u when the output does not fit (the caller then
+// stores the entry, ref otezip.c:846-850).
+OTZ_DEV u32 otz_deflate_entry(otz_enc_lds &L, const u8 *src, u32 n, u8 *dst, u32 cap) {
+	const u32 lane = otz_tid ();
+	otz_enc_state S;
+	S.acc = 0;
+	S.nacc = 0;
+	S.stage_fill = 0;
+	S.out_pos = 0;
+	S.cap = cap;
+	S.dst = dst;
+	S.overflow = false;
+	for (u32 i = lane; i < OTZ_ENC_HASH; i += OTZ_ENC_NT) {
+		L.head[i] = 0;
+	}
+	u32 loaded = 0, p = 0;
+	otz_enc_put (L, S, 2u, 3); // BFINAL = 0, BTYPE = 01 (fixed Huffman)
+	otz_sync ();
+	while (p < n && !S.overflow) {
+		// keep [p - MAXDIST, p + 258 + 64) resident in the ring
+		if (loaded < n && p + 258u + 64u > loaded) {
+			u32 upto = loaded + 1024u;
+			otz_sync ();
+			for (u32 q = loaded + lane; q < upto && q < n; q += OTZ_ENC_NT) {
+				L.win[q & OTZ_ENC_WMASK] = src[q];
+			}
+			loaded = upto < n ? upto : n;
+			otz_sync ();
+		}
+		u32 len = 0, dist = 0;
+		u32 h = 0;
+		const bool can_hash = p + 3u <= n;
+		if (can_hash) {
+			h = otz_enc_hash (L.win[p & OTZ_ENC_WMASK], L.win[(p + 1u) & OTZ_ENC_WMASK], L.win[(p + 2u) & OTZ_ENC_WMASK]);
+			dist = (p - (u32)L.head[h]) & 0xFFFFu;
+			if (dist >= 1u && dist <= OTZ_ENC_MAXDIST && dist <= p) {
+				u32 maxlen = n - p < 258u ? n - p : 258u;
+				len = maxlen;
+				for (u32 k = 0; k < 320u; k += 64u) {
+					u32 idx = k + lane;
+					bool same = idx < maxlen && L.win[(p + idx) & OTZ_ENC_WMASK] == L.win[(p - dist + idx) & OTZ_ENC_WMASK];
+					u64 diff = otz_ballot (!same);
+					if (diff) {
+						u32 first = (u32)__builtin_ctzll (diff);
+						len = k + first < maxlen ? k + first : maxlen;
+						break;
+					}
+				}
+				if (len < 3u) {
+					len = 0;
+				}
+			}
+		}
+		otz_sync (); // every lane has read head[] and the window
+		if (len) {
+			otz_enc_put_match (L, S, len, dist);
+			// the whole match enters the hash table at once
+			for (u32 j = lane; j < len; j += OTZ_ENC_NT) {
+				u32 q = p + j;
+				if (q + 3u <= n) {
+					u32 hq = otz_enc_hash (L.win[q & OTZ_ENC_WMASK], L.win[(q + 1u) & OTZ_ENC_WMASK], L.win[(q + 2u) & OTZ_ENC_WMASK]);
+					L.head[hq] = (u16)q;
+				}
+			}
+			p += len;
+		} else {
+			otz_enc_put_litlen (L, S, L.win[p & OTZ_ENC_WMASK]);
+			if (can_hash && lane == 0) {
+				L.head[h] = (u16)p;
+			}
+			p += 1u;
+		}
+		otz_sync ();
+	}
+	otz_enc_put_litlen (L, S, 256u); // end of the fixed block
+	// final block: stored, empty (BFINAL = 1, BTYPE = 00, pad to a byte, LEN = 0, NLEN = 0xFFFF)
+	otz_enc_put (L, S, 1u, 3);
+	if (S.nacc & 7u) {
+		otz_enc_put (L, S, 0u, 8u - (S.nacc & 7u));
+	}
+	otz_enc_put (L, S, 0xFFFF0000u, 32);
+	// drain the accumulator (whole bytes by construction)
+	while (S.nacc) {
+		if (lane == 0) {
+			reinterpret_cast<u8 *> (L.out_w)[S.stage_fill] = (u8)S.acc;
+		}
+		S.acc >>= 8;
+		S.nacc -= 8u;
+		S.stage_fill += 1u;
+		if (S.stage_fill == OTZ_ENC_OUT) {
+			otz_enc_flush_stage (L, S);
+		}
+	}
+	otz_enc_flush_stage (L, S);
+	return S.overflow ? ~0u : S.out_pos;
+}
+
+// One buffer of an encode batch: otezip_compress_data (ref src/lib/otezip.c:788-1076) for it.
+//  * method 8: DEFLATE as above; "not smaller than the input" or "does not fit" -> STORE (:846-850)
+//  * methods 93 / 100 / 97: the reference's writers only add bytes to the input,
+//    so its own fallback rule always stores such entries; STORE is written directly
+//  * method 14 (private RLE tokens, ref lzma-enc.inc.c:110-161): not encoded here yet -> STORE
+//  * zero-length input -> STORE with size 0 (:793-801)
+// The CRC-32 of the input (ref :1124) is taken by otz_enc_crc_kernel.
+OTZ_DEV void otz_encode_entry(otz_enc_lds &L, const u8 *src, u8 *dst, const ozg_enc_entry &e, ozg_enc_result *res) {
+	const u32 lane = otz_tid ();
+	const u8 *in = src + e.src_off;
+	u8 *out = dst + e.dst_off;
+	bool stored = true;
+	if (((uintptr_t)out & 15u) != 0 || e.dst_cap < e.src_size) {
+		if (lane == 0) {
+			res->status = OZG_ST_INTERNAL;
+			res->comp_size = 0;
+			res->method = e.method;
+			res->flags = 0;
+		}
+		return;
+	}
+	if (e.method == OZG_METHOD_DEFLATE && e.src_size > 0) {
+		u32 cs = otz_deflate_entry (L, in, e.src_size, out, e.dst_cap);
+		stored = cs >= e.src_size; // did not fit, or not smaller: ref otezip.c:846-850
+		if (!stored && lane == 0) {
+			res->status = OZG_ST_OK;
+			res->comp_size = cs;
+		}
+	}
+	if (stored) {
+		u32 n = e.src_size;
+		for (u32 c = lane; c < (n >> 4); c += OTZ_ENC_NT) {
+			otz_st16_aligned (out + 16ull * c, otz_ld16 (in + 16ull * c));
+		}
+		for (u32 i = (n & ~15u) + lane; i < n; i += OTZ_ENC_NT) {
+			out[i] = in[i];
+		}
+		if (lane == 0) {
+			res->status = OZG_ST_OK;
+			res->comp_size = n;
+		}
+	}
+	if (lane == 0) {
+		res->method = stored ? (uint16_t)OZG_METHOD_STORE : (uint16_t)OZG_METHOD_DEFLATE;
+		res->flags = 0;
+	}
+}

@@ -18,9 +18,11 @@
 #include <string.h>
 
 #include "otz_dispatch.h"
+#include "otz_deflate_enc.h"
 
 static_assert (sizeof (ozg_entry) == 32, "ozg_entry ABI");
 static_assert (sizeof (ozg_result) == 16, "ozg_result ABI");
+static_assert (sizeof (ozg_enc_entry) == 32 && sizeof (ozg_enc_result) == 16, "encode ABI");
 static_assert (sizeof (otz_inflate_lds) <= 80 * 1024, "two inflate workgroups per CU");
 
 static_assert (OTZ_NT * OTZ_S_BITS / 8 + 512 <= OTZ_STAGE_BYTES, "stage must cover one round of input");
@@ -65,6 +67,38 @@ otz_crc32_kernel(const u8 *buf, const u64 *off, const u32 *len, u32 *crc, u32 n)
 	u32 R = otz_stream_crc (L, buf + off[i], nullptr, m, false);
 	if (otz_tid () == 0) {
 		crc[i] = ~(otz_gf_mul (0xFFFFFFFFu, otz_xpow_bytes (m)) ^ R);
+	}
+}
+
+// DEFLATE encode / STORE of n independent buffers: one wavefront each (26 KB LDS)
+extern "C" __global__ void __launch_bounds__ (64)
+otz_encode_kernel(const u8 *src, u8 *dst, const ozg_enc_entry *entries, ozg_enc_result *results, u32 n) {
+	extern __shared__ __attribute__ ((aligned (16))) u8 otz_smem[];
+	u32 i = blockIdx.x;
+	if (i >= n) {
+		return;
+	}
+	otz_enc_lds &L = *reinterpret_cast<otz_enc_lds *> (otz_smem);
+	ozg_enc_entry e = entries[i];
+	otz_encode_entry (L, src, dst, e, &results[i]);
+}
+
+// CRC-32 of every input buffer of an encode batch (ref src/lib/otezip.c:1124)
+extern "C" __global__ void __launch_bounds__ (256)
+otz_enc_crc_kernel(const u8 *src, const ozg_enc_entry *entries, ozg_enc_result *results, u32 n) {
+	extern __shared__ __attribute__ ((aligned (16))) u8 otz_smem[];
+	u32 i = blockIdx.x;
+	if (i >= n) {
+		return;
+	}
+	otz_copy_lds &L = *reinterpret_cast<otz_copy_lds *> (otz_smem);
+	otz_crc_load_slice4 (L.t4);
+	otz_crc_load_adv4k (L.a4);
+	otz_sync ();
+	u32 m = entries[i].src_size;
+	u32 R = otz_stream_crc (L, src + entries[i].src_off, nullptr, m, false);
+	if (otz_tid () == 0) {
+		results[i].crc32 = ~(otz_gf_mul (0xFFFFFFFFu, otz_xpow_bytes (m)) ^ R);
 	}
 }
 
@@ -154,6 +188,10 @@ int ozg_init(int device) {
 		(int)sizeof (otz_copy_lds)));
 	OZG_HIP (hipFuncSetAttribute ((const void *)otz_crc32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
 		(int)sizeof (otz_copy_lds)));
+	OZG_HIP (hipFuncSetAttribute ((const void *)otz_enc_crc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+		(int)sizeof (otz_copy_lds)));
+	OZG_HIP (hipFuncSetAttribute ((const void *)otz_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+		(int)sizeof (otz_enc_lds)));
 	g_device = device;
 	g_ready = true;
 	g_err[0] = 0;
@@ -270,6 +308,90 @@ int ozg_decode_batch_host(const void *src, uint64_t src_len, void *dst, uint64_t
 	}
 	OZG_HIP (hipMemcpyAsync (dst, g_stage.d_dst, dst_len, hipMemcpyDeviceToHost, nullptr));
 	OZG_HIP (hipMemcpyAsync (results, g_stage.d_res, (size_t)n * sizeof (ozg_result), hipMemcpyDeviceToHost, nullptr));
+	OZG_HIP (hipStreamSynchronize (nullptr));
+	return OZG_OK;
+}
+
+uint64_t ozg_compress_bound(uint16_t method, uint64_t n) {
+	uint64_t b;
+	switch (method) {
+	case OZG_METHOD_DEFLATE: b = n + (n >> 3) + 75u; break; /* compressBound, ref deflate.inc.c:72-77 */
+	case OZG_METHOD_ZSTD: b = n + 1024u; break;             /* ref otezip.c:860 */
+	case OZG_METHOD_LZFSE: b = n + n / 10u + 100u; break;   /* :931 */
+	case OZG_METHOD_LZMA: b = n + 13u + n / 8u; break;      /* :975 */
+	case OZG_METHOD_BROTLI: b = 2u * n + 64u; break;        /* :1019 */
+	default: b = n; break;
+	}
+	return b < 16u ? 16u : b;
+}
+
+int ozg_encode_batch_device(const void *d_src, uint64_t src_len, void *d_dst, uint64_t dst_len,
+	const ozg_enc_entry *d_entries, ozg_enc_result *d_results, uint32_t n, void *stream) {
+	int rc = need_ready ();
+	if (rc != OZG_OK) {
+		return rc;
+	}
+	(void)src_len;
+	(void)dst_len;
+	if (n == 0) {
+		return OZG_OK;
+	}
+	if (!d_src || !d_dst || !d_entries || !d_results || ((uintptr_t)d_dst & 15u)) {
+		snprintf (g_err, sizeof (g_err), "null device pointer or d_dst not 16-byte aligned");
+		return OZG_E_ARG;
+	}
+	hipStream_t s = (hipStream_t)stream;
+	hipLaunchKernelGGL (otz_encode_kernel, dim3 (n), dim3 (64), sizeof (otz_enc_lds), s, (const u8 *)d_src, (u8 *)d_dst,
+		d_entries, d_results, n);
+	OZG_HIP (hipGetLastError ());
+	hipLaunchKernelGGL (otz_enc_crc_kernel, dim3 (n), dim3 (256), sizeof (otz_copy_lds), s, (const u8 *)d_src, d_entries,
+		d_results, n);
+	OZG_HIP (hipGetLastError ());
+	return OZG_OK;
+}
+
+int ozg_encode_batch_host(const void *src, uint64_t src_len, void *dst, uint64_t dst_len,
+	const ozg_enc_entry *entries, ozg_enc_result *results, uint32_t n) {
+	int rc = need_ready ();
+	if (rc != OZG_OK) {
+		return rc;
+	}
+	if (n == 0) {
+		return OZG_OK;
+	}
+	if (!src || !dst || !entries || !results) {
+		snprintf (g_err, sizeof (g_err), "null pointer");
+		return OZG_E_ARG;
+	}
+	for (uint32_t i = 0; i < n; i++) {
+		const ozg_enc_entry &e = entries[i];
+		if (e.src_off + e.src_size > src_len || (e.dst_off & 15u) || e.dst_off + e.dst_cap > dst_len || e.dst_cap < e.src_size) {
+			snprintf (g_err, sizeof (g_err), "encode entry %u: offsets outside the buffers, dst_off not a multiple of 16, or dst_cap < src_size", i);
+			return OZG_E_ARG;
+		}
+	}
+	std::lock_guard<std::mutex> lk (g_mu);
+	if ((rc = grow (&g_stage.d_src, &g_stage.src_cap, src_len + 64)) != OZG_OK) {
+		return rc;
+	}
+	if ((rc = grow (&g_stage.d_dst, &g_stage.dst_cap, dst_len + 64)) != OZG_OK) {
+		return rc;
+	}
+	if ((rc = grow (&g_stage.d_ent, &g_stage.ent_cap, (size_t)n * sizeof (ozg_enc_entry))) != OZG_OK) {
+		return rc;
+	}
+	if ((rc = grow (&g_stage.d_res, &g_stage.res_cap, (size_t)n * sizeof (ozg_enc_result))) != OZG_OK) {
+		return rc;
+	}
+	OZG_HIP (hipMemcpyAsync (g_stage.d_src, src, src_len, hipMemcpyHostToDevice, nullptr));
+	OZG_HIP (hipMemcpyAsync (g_stage.d_ent, entries, (size_t)n * sizeof (ozg_enc_entry), hipMemcpyHostToDevice, nullptr));
+	rc = ozg_encode_batch_device (g_stage.d_src, src_len, g_stage.d_dst, dst_len, (const ozg_enc_entry *)g_stage.d_ent,
+		(ozg_enc_result *)g_stage.d_res, n, nullptr);
+	if (rc != OZG_OK) {
+		return rc;
+	}
+	OZG_HIP (hipMemcpyAsync (dst, g_stage.d_dst, dst_len, hipMemcpyDeviceToHost, nullptr));
+	OZG_HIP (hipMemcpyAsync (results, g_stage.d_res, (size_t)n * sizeof (ozg_enc_result), hipMemcpyDeviceToHost, nullptr));
 	OZG_HIP (hipStreamSynchronize (nullptr));
 	return OZG_OK;
 }

@@ -736,58 +736,56 @@ void zip_source_free(zip_source_t *src) {
 	free (src);
 }
 
-/* CRC-32 of a host buffer, on the GPU (otezip_crc32 of ref :1124) */
-static int gpu_crc32(const void *buf, zip_uint64_t len, uint32_t *crc) {
-	if (len == 0) {
-		*crc = 0;
-		return 0;
-	}
-	int rc = -1;
-	uint8_t *d = (uint8_t *)ozg_malloc ((size_t)len + 64);
-	uint64_t *d_off = (uint64_t *)ozg_malloc (16);
-	uint32_t *d_len = (uint32_t *)ozg_malloc (16), *d_crc = (uint32_t *)ozg_malloc (16);
-	uint64_t off = 0;
-	uint32_t l32 = (uint32_t)len;
-	if (d && d_off && d_len && d_crc && ozg_memcpy_h2d (d, buf, (size_t)len, NULL) == OZG_OK &&
-		ozg_memcpy_h2d (d_off, &off, 8, NULL) == OZG_OK && ozg_memcpy_h2d (d_len, &l32, 4, NULL) == OZG_OK &&
-		ozg_crc32_batch_device (d, d_off, d_len, d_crc, 1, NULL) == OZG_OK &&
-		ozg_memcpy_d2h (crc, d_crc, 4, NULL) == OZG_OK && ozg_stream_sync (NULL) == OZG_OK) {
-		rc = 0;
-	}
-	ozg_free (d);
-	ozg_free (d_off);
-	ozg_free (d_len);
-	ozg_free (d_crc);
-	return rc;
-}
-
-/* The encode side of otezip_compress_data (ref :788-1076) as far as this round goes:
- * the reference's zstd / lzfse / brotli writers only ever ADD bytes, so its own
- * "not smaller -> STORE" rule turns every such entry into STORE and STORE
- * is what is written here for them too.  DEFLATE and the LZMA token format are the
- * two methods that can shrink data; their GPU encoders are not built yet, and until
- * then those entries are stored as well (valid archive, ratio 1.0; said on stderr). */
+/* otezip_compress_data (ref :788-1076) + the CRC of :1124 for one source buffer, on the GPU:
+ * one ozg_encode_batch_host call returns the payload to write, the method it ended up
+ * with (the reference's "not smaller -> STORE" rule is applied on the device) and the
+ * CRC-32 of the input.  Methods 93/100/97 always end as STORE, exactly as in the
+ * reference, whose writers for them only add bytes.  Method 14 (private RLE
+ * tokens) is stored too for now: its encoder is not built yet. */
 static int store_entry(zip_t *za, struct otezip_entry *e, zip_source_t *src) {
-	static int warned;
-	if ((e->method == OTEZIP_METHOD_DEFLATE || e->method == OTEZIP_METHOD_LZMA) && src->len && !warned) {
-		fprintf (stderr, "otezip-amd: GPU encoder for method %u not available yet, storing\n", e->method);
-		warned = 1;
-	}
-	if (!gpu_up () || gpu_crc32 (src->buf, src->len, &e->crc32) != 0) {
+	if (!gpu_up ()) {
 		return -1;
 	}
-	e->method = OTEZIP_METHOD_STORE;
-	e->uncomp_size = e->comp_size = (uint32_t)src->len;
+	uint32_t n = (uint32_t)src->len;
+	uint64_t cap = ozg_compress_bound (e->method, n);
+	uint8_t *out = (uint8_t *)malloc ((size_t)cap + 32);
+	uint8_t *in = (uint8_t *)malloc ((size_t)n + 32);
+	if (!out || !in) {
+		free (out);
+		free (in);
+		return -1;
+	}
+	if (n) {
+		memcpy (in, src->buf, n);
+	}
+	ozg_enc_entry ee;
+	memset (&ee, 0, sizeof (ee));
+	ee.src_size = n;
+	ee.dst_cap = (uint32_t)cap;
+	ee.method = e->method;
+	ozg_enc_result er;
+	memset (&er, 0, sizeof (er));
+	int rc = ozg_encode_batch_host (in, (uint64_t)n + 16, out, cap + 16, &ee, &er, 1);
+	free (in);
+	if (rc != OZG_OK || er.status != OZG_ST_OK) {
+		fprintf (stderr, "otezip-amd: GPU encode failed: %s\n", ozg_last_error ());
+		free (out);
+		return -1;
+	}
+	e->method = er.method;
+	e->crc32 = er.crc32;
+	e->uncomp_size = n;
+	e->comp_size = er.comp_size;
 	long pos = ftell (za->fp);
 	if (pos < 0 || (uint64_t)pos > UINT32_MAX) {
+		free (out);
 		return -1;
 	}
 	e->local_hdr_ofs = (uint32_t)pos;
 	write_lfh (za->fp, e);
-	if (src->len && fwrite (src->buf, 1, (size_t)src->len, za->fp) != src->len) {
-		return -1;
-	}
-	return 0;
+	int ok = er.comp_size == 0 || fwrite (out, 1, er.comp_size, za->fp) == er.comp_size;
+	free (out);
+	return ok ? 0 : -1;
 }
 
 zip_int64_t zip_file_add(zip_t *za, const char *name, zip_source_t *src, zip_flags_t flags) {

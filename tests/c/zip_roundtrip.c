@@ -74,6 +74,7 @@ static int do_setcomp(const char *path) {
 	if (!za) {
 		return 10;
 	}
+	za->default_method = ZIP_CM_DEFLATE; /* what the reference's CLI does for -z deflate (src/main.c:190) */
 	char *buf = (char *)malloc (N);
 	memcpy (buf, expected, N);
 	zip_source_t *src = zip_source_buffer (za, buf, N, 1);

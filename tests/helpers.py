@@ -109,3 +109,42 @@ def check_against_oracle(items, results, what=""):
             assert bool(r.flags & F_REF_FALSE_REJECT) == bool(o["verdict"] & O.V_REF_FALSE_REJECT), tag + ": F2 flag"
             assert bool(r.flags & F_SHORT_STREAM) == bool(o["verdict"] & O.V_SHORT_STREAM), tag + ": F12 flag"
         assert set(guard[-16:]) <= {0xCD}, tag + ": wrote past the entry's region"
+
+
+class OzgEncEntry(C.Structure):
+    _fields_ = [("src_off", C.c_uint64), ("dst_off", C.c_uint64), ("src_size", C.c_uint32), ("dst_cap", C.c_uint32),
+                ("method", C.c_uint16), ("level", C.c_uint16), ("reserved", C.c_uint32)]
+
+
+class OzgEncResult(C.Structure):
+    _fields_ = [("status", C.c_int32), ("comp_size", C.c_uint32), ("crc32", C.c_uint32), ("method", C.c_uint16),
+                ("flags", C.c_uint16)]
+
+
+def enc_layout(bufs, method=8):
+    """[(bytes)] -> (src, entries, dst_len) for the encode ABI."""
+    n = len(bufs)
+    ents = (OzgEncEntry * max(n, 1))()
+    src = bytearray()
+    dst_off = 0
+    for i, b in enumerate(bufs):
+        src += b"\x11" * ((5 * i + 1) % 7)
+        ents[i].src_off = len(src)
+        src += b
+        ents[i].src_size = len(b)
+        cap = max(len(b) + len(b) // 8 + 75, 16)
+        ents[i].dst_cap = cap
+        ents[i].dst_off = dst_off
+        ents[i].method = method if not isinstance(method, (list, tuple)) else method[i]
+        dst_off += (cap + 15) & ~15
+    return bytes(src) + b"\x11" * 16, ents, dst_off + 16
+
+
+def emu_encode(bufs, method=8):
+    src, ents, dst_len = enc_layout(bufs, method)
+    dst = C.create_string_buffer(b"\xCD" * dst_len, dst_len)
+    res = (OzgEncResult * max(len(bufs), 1))()
+    L = emu_lib()
+    L.emu_encode_batch.argtypes = [C.c_char_p, C.c_void_p, C.POINTER(OzgEncEntry), C.POINTER(OzgEncResult), C.c_uint32]
+    L.emu_encode_batch(src, dst, ents, res, len(bufs))
+    return [(res[i], dst.raw[ents[i].dst_off:ents[i].dst_off + res[i].comp_size]) for i in range(len(bufs))]

@@ -3,6 +3,7 @@
 // 256-lane workgroup, one workgroup at a time.  Built by tests/simt_emu/Makefile
 // into tests/simt_emu/libotz_emu.so, optionally with -fsanitize=address.
 #include "otz_dispatch.h"
+#include "otz_deflate_enc.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -81,3 +82,49 @@ extern "C" int emu_decode_batch(const void *src, uint64_t src_len, void *dst, ui
 
 extern "C" uint32_t emu_lds_bytes_inflate(void) { return (uint32_t)sizeof (otz_inflate_lds); }
 extern "C" uint32_t emu_lds_bytes_copy(void) { return (uint32_t)sizeof (otz_copy_lds); }
+
+// ---- encode side: one 64-thread workgroup per buffer (CRC is left to the caller in emulation)
+namespace {
+struct enc_args {
+	otz_emu_block *blk;
+	u32 tid;
+	void *lds;
+	const u8 *src;
+	u8 *dst;
+	const ozg_enc_entry *e;
+	ozg_enc_result *r;
+};
+void *enc_thread(void *p) {
+	enc_args *a = (enc_args *)p;
+	otz_emu_self.tid = a->tid;
+	otz_emu_self.blk = a->blk;
+	otz_encode_entry (*(otz_enc_lds *)a->lds, a->src, a->dst, *a->e, a->r);
+	return nullptr;
+}
+} // namespace
+
+extern "C" int emu_encode_batch(const void *src, void *dst, const ozg_enc_entry *entries, ozg_enc_result *results, uint32_t n) {
+	const u32 NT = OTZ_ENC_NT;
+	for (uint32_t i = 0; i < n; i++) {
+		otz_emu_block blk;
+		blk.nthreads = NT;
+		pthread_barrier_init (&blk.block_bar, nullptr, NT);
+		pthread_barrier_init (&blk.wave_bar[0], nullptr, NT);
+		void *lds = aligned_alloc (64, (sizeof (otz_enc_lds) + 63) & ~(size_t)63);
+		memset (lds, 0xA5, sizeof (otz_enc_lds));
+		results[i].status = -999;
+		std::vector<enc_args> args (NT);
+		std::vector<pthread_t> th (NT);
+		for (u32 t = 0; t < NT; t++) {
+			args[t] = { &blk, t, lds, (const u8 *)src, (u8 *)dst, &entries[i], &results[i] };
+			pthread_create (&th[t], nullptr, enc_thread, &args[t]);
+		}
+		for (u32 t = 0; t < NT; t++) {
+			pthread_join (th[t], nullptr);
+		}
+		free (lds);
+		pthread_barrier_destroy (&blk.block_bar);
+		pthread_barrier_destroy (&blk.wave_bar[0]);
+	}
+	return 0;
+}

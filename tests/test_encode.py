@@ -1,0 +1,86 @@
+"""The encode side (rows a9/a10 of SURVEY section 8): otezip_compress_data + the zip_file_add
+CRC, through ozg_encode_batch_*.  The reference's DEFLATE encoder emits invalid DEFLATE
+(SURVEY F3), so byte parity is meaningless; the bar is parity rule 5:
+  * valid: an independent inflate (host zlib), the oracle's restatement of the REFERENCE's own
+    inflate (rc == 0, i.e. no F2 false reject) and this library's GPU inflate all return the input;
+  * ratio_new >= 0.98 * ratio_ref, ratio_ref from the reference encoder's output size on the
+    same buffer (golden, generated from the reference by oracle/gen_golden.py);
+  * the "not smaller -> STORE" rule (ref src/lib/otezip.c:846-850) and the STORE outcome of the
+    reference's byte-adding framings 93/100/97 (F9)."""
+import os
+import zlib
+
+import pytest
+
+import golden
+from helpers import O, emu_encode
+from otezip_amd import corpus
+
+
+def check_roundtrip(buf, method_written, payload):
+    if method_written == 0:
+        assert payload == buf
+        return
+    assert method_written == 8
+    assert zlib.decompress(payload, -15) == buf                       # independent decoder
+    o = O.extract_entry(8, payload, len(buf), zlib.crc32(buf))
+    assert o["rc"] == 0 and o["out"] == buf, "the reference's inflate must accept it too (F2-safe tail)"
+    assert not (o["verdict"] & O.V_REF_FALSE_REJECT)
+
+
+def test_kernel_body_under_emulation():
+    bufs = [b"", b"a", b"abc", b"hello hello hello hello", corpus.gen_text(8, 3000), b"A" * 5000, os.urandom(2000),
+            (b"abc" * 3000)[:8000], corpus.gen_text(9, 100)]
+    out = emu_encode(bufs)
+    for b, (r, payload) in zip(bufs, out):
+        assert r.status == 1
+        check_roundtrip(b, r.method, payload)
+    assert out[6][0].method == 0 and out[5][0].method == 8           # random data is stored, runs compress
+    # ratio vs the reference encoder on the golden seeds that are small enough to emulate
+    sizes = {(g["seed"], g["size"]): g for g in golden.load()["ref_deflate_sizes"]}
+    for (seed, size), buf_out in (((8, 3000), out[4]), ((9, 100), out[8])):
+        ref_size = sizes[(seed, size)]["ref_deflate_size"]
+        mine = buf_out[0].comp_size
+        assert size / mine >= 0.98 * (size / ref_size), (seed, size, mine, ref_size)
+
+
+def test_framings_that_only_add_bytes_end_as_store_under_emulation():
+    b = corpus.gen_text(3, 1500)
+    for m in (0, 93, 100, 97, 14):
+        (r, payload), = emu_encode([b], method=m)
+        assert r.status == 1 and r.method == 0 and payload == b
+
+
+@pytest.mark.gpu
+def test_gpu_encode_roundtrip_and_ratio(gpu_lib):
+    g = golden.load()["ref_deflate_sizes"]
+    bufs = [corpus.gen_text(e["seed"], e["size"]) for e in g] + [b"", b"x", os.urandom(70000), b"\0" * 200000,
+                                                                   corpus.gen_text(11, 300000)]
+    out = gpu_lib.encode_batch_host(bufs, 8)
+    for b, (method, payload, crc) in zip(bufs, out):
+        assert crc == zlib.crc32(b) & 0xFFFFFFFF                      # CRC of the input, ref otezip.c:1124
+        check_roundtrip(b, method, payload)
+    for e, (method, payload, crc) in zip(g, out):
+        ratio_new, ratio_ref = e["size"] / len(payload), e["size"] / e["ref_deflate_size"]
+        assert ratio_new >= 0.98 * ratio_ref, (e, len(payload))
+    # and the GPU decoder reads what the GPU encoder wrote
+    items, blob = [], bytearray()
+    for b, (method, payload, crc) in zip(bufs, out):
+        items.append((method, len(blob), len(payload), len(b), crc))
+        blob += payload
+    dec = gpu_lib.decode_batch_host(bytes(blob) + b"\0" * 16, items)
+    for i, b in enumerate(bufs):
+        assert dec.ok(i) and dec.data(i) == b and dec.results[i].flags == 0
+
+
+@pytest.mark.gpu
+def test_gpu_config5_shape(gpu_lib):
+    """configs[4] at reduced count: 500 x 64 KiB buffers, level-6 request, round trip exact,
+    every ratio above the reference's (which is ~1.35 on this corpus)."""
+    bufs = [corpus.gen_text(20000 + i, 65536) for i in range(500)]
+    out = gpu_lib.encode_batch_host(bufs, 8)
+    total = 0
+    for b, (method, payload, crc) in zip(bufs, out):
+        assert method == 8 and zlib.decompress(payload, -15) == b and crc == zlib.crc32(b) & 0xFFFFFFFF
+        total += len(payload)
+    assert 500 * 65536 / total > 1.5

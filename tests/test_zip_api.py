@@ -132,3 +132,5 @@ def test_add_then_set_compression_then_read_back(prog, tmp_path):
     assert rc == 0, (rc, err)
     with zipfile.ZipFile(p) as z:  # and an independent reader accepts the archive
         assert z.read("hello.txt") == b"A" * 4096 and z.read("empty") == b""
+        assert z.getinfo("hello.txt").compress_type == zipfile.ZIP_DEFLATED   # written by the GPU encoder
+        assert z.getinfo("hello.txt").compress_size < 100
