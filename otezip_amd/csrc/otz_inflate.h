@@ -739,6 +739,25 @@ OTZ_DEV void otz_parse_header_b(otz_inflate_lds &L, u32 p, u64 avail) {
 
 // ------------------------------------------------------------------- passes
 
+// The visited-token-start bitmap of a lane's pass-A path lives in registers: every access
+// goes through compile-time indices (a runtime-indexed array would be demoted to scratch
+// memory, i.e. global-memory round trips inside the hottest loop).
+#define OTZ_VIS_WORDS (OTZ_S_BITS / 32u)
+OTZ_DEV void otz_vis_merge(u32 (&vis)[OTZ_VIS_WORDS], u32 k, u32 bits) {
+#pragma unroll
+	for (u32 i = 0; i < OTZ_VIS_WORDS; i++) {
+		vis[i] |= k == i ? bits : 0u;
+	}
+}
+OTZ_DEV u32 otz_vis_pick(const u32 (&vis)[OTZ_VIS_WORDS], u32 k) {
+	u32 w = 0;
+#pragma unroll
+	for (u32 i = 0; i < OTZ_VIS_WORDS; i++) {
+		w |= k == i ? vis[i] : 0u;
+	}
+	return w;
+}
+
 struct otz_path {
 	u32 exit;  // exit word
 	u32 bytes; // output bytes of the tokens walked
@@ -750,7 +769,7 @@ struct otz_path {
 #define OTZ_MODE_PREFIX 2 // from the speculative start up to `stop`
 
 template <int MODE>
-OTZ_DEV otz_path otz_walk(const otz_inflate_lds &L, const otz_dec &D, u32 start, u32 s, u32 e, u32 limit_bits, u32 stop, u32 (&vis)[8]) {
+OTZ_DEV otz_path otz_walk(const otz_inflate_lds &L, const otz_dec &D, u32 start, u32 s, u32 e, u32 limit_bits, u32 stop, u32 (&vis)[OTZ_VIS_WORDS]) {
 	otz_path P;
 	P.bytes = 0;
 	P.syncq = ~0u;
@@ -772,14 +791,7 @@ OTZ_DEV otz_path otz_walk(const otz_inflate_lds &L, const otz_dec &D, u32 start,
 			}
 			u32 k = rel >> 5;
 			if (k != ck) {
-				vis[0] |= ck == 0 ? cw : 0u;
-				vis[1] |= ck == 1 ? cw : 0u;
-				vis[2] |= ck == 2 ? cw : 0u;
-				vis[3] |= ck == 3 ? cw : 0u;
-				vis[4] |= ck == 4 ? cw : 0u;
-				vis[5] |= ck == 5 ? cw : 0u;
-				vis[6] |= ck == 6 ? cw : 0u;
-				vis[7] |= ck == 7 ? cw : 0u;
+				otz_vis_merge (vis, ck, cw);
 				cw = 0;
 				ck = k;
 			}
@@ -787,9 +799,7 @@ OTZ_DEV otz_path otz_walk(const otz_inflate_lds &L, const otz_dec &D, u32 start,
 		}
 		if (MODE == OTZ_MODE_B) {
 			u32 k = rel >> 5;
-			u32 wa = k & 2u ? (k & 1u ? vis[3] : vis[2]) : (k & 1u ? vis[1] : vis[0]);
-			u32 wb = k & 2u ? (k & 1u ? vis[7] : vis[6]) : (k & 1u ? vis[5] : vis[4]);
-			u32 w = k & 4u ? wb : wa;
+			u32 w = otz_vis_pick (vis, k);
 			if ((w >> (rel & 31u)) & 1u) {
 				P.syncq = pos;
 				break;
@@ -813,14 +823,7 @@ OTZ_DEV otz_path otz_walk(const otz_inflate_lds &L, const otz_dec &D, u32 start,
 		P.bytes += t.kind == OTZ_K_LIT ? 1u : t.val;
 	}
 	if (MODE == OTZ_MODE_A) {
-		vis[0] |= ck == 0 ? cw : 0u;
-		vis[1] |= ck == 1 ? cw : 0u;
-		vis[2] |= ck == 2 ? cw : 0u;
-		vis[3] |= ck == 3 ? cw : 0u;
-		vis[4] |= ck == 4 ? cw : 0u;
-		vis[5] |= ck == 5 ? cw : 0u;
-		vis[6] |= ck == 6 ? cw : 0u;
-		vis[7] |= ck == 7 ? cw : 0u;
+		otz_vis_merge (vis, ck, cw);
 	}
 	return P;
 }
@@ -1201,7 +1204,7 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 			OTZ_COUNT (L, J, OTZ_P_ROUNDS, 1);
 			// pass A
 			const u32 s = p0 + tid * OTZ_S_BITS, e = s + OTZ_S_BITS;
-			u32 vis[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+			u32 vis[OTZ_VIS_WORDS] = {};
 			otz_path A = otz_walk<OTZ_MODE_A> (L, D, s, s, e, limit_bits, 0, vis);
 			L.exits[tid] = A.exit;
 			otz_sync ();
@@ -1257,7 +1260,7 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 				} else {
 					u32 pre = 0;
 					if (q != s) {
-						u32 dummy[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+						u32 dummy[OTZ_VIS_WORDS] = {};
 						pre = otz_walk<OTZ_MODE_PREFIX> (L, D, s, s, e, limit_bits, q, dummy).bytes;
 					}
 					bytes = wbytes + A.bytes - pre;

@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Secondary measurements for DESIGN.md / profiles (not the headline bench):
+  * DEFLATE encode, 10 000 x 64 KiB buffers resident in HBM (BASELINE configs[4] shape)
+  * private-zstd framing decode, 10 000 x 256 KiB (configs[2] shape, scaled by --zstd-entries)
+  * lzfse + BROT framing decode, 64 KiB payloads (configs[3] shape)
+  * host-buffer (PCIe-inclusive) DEFLATE decode through ozg_decode_batch_host"""
+import ctypes as C
+import json
+import os
+import sys
+import time
+import zlib
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import otezip_amd as oz
+from otezip_amd import corpus, _native as N
+
+
+def timed(fn, steps=5, warm=1):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(steps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / steps * 1e-3
+
+
+def decode_resident(arc, ents, flags):
+    tab = [(e["method"], e["data_off"], e["comp_size"], e["uncomp_size"], e["crc32"]) for e in ents]
+    et, dst_len = oz.make_entries(tab)
+    dev = torch.device("cuda", 0)
+    d_src = torch.frombuffer(bytearray(arc), dtype=torch.uint8).to(dev)
+    d_dst = torch.empty(dst_len + 64, dtype=torch.uint8, device=dev)
+    d_ent = torch.frombuffer(bytearray(bytes(et)), dtype=torch.uint8).to(dev)
+    d_res = torch.zeros(len(tab) * 16, dtype=torch.uint8, device=dev)
+    s = torch.cuda.current_stream()
+    L = oz.lib()
+
+    def run():
+        N.check(L.ozg_decode_batch_device_ex(d_src.data_ptr(), d_src.numel(), d_dst.data_ptr(), d_dst.numel(),
+                                             d_ent.data_ptr(), d_res.data_ptr(), len(tab), s.cuda_stream, flags))
+    t = timed(run)
+    res = np.frombuffer(d_res.cpu().numpy().tobytes(), dtype=np.uint32).reshape(-1, 4)
+    assert (res[:, 0] == 1).all() and all(res[i, 2] == e["crc32"] for i, e in enumerate(ents))
+    comp = sum(e["comp_size"] for e in ents)
+    out = sum(e["uncomp_size"] for e in ents)
+    return dict(ms=t * 1e3, out_GiBps=out / t / 2**30, algo_GBps=(comp + out) / t / 1e9, frac=(comp + out) / t / 8e12)
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+    report = {}
+    # archives first (forks), GPU afterwards
+    arc_z, ents_z = corpus.build_archive(max(n // 4, 100), 262144, methods=(93,))
+    arc_m, ents_m = corpus.build_archive(n, 65536, methods=(100, 97))
+    arc_d, ents_d = corpus.build_archive(min(n, 4000), 65536, methods=(8,))
+    bufs = [corpus.gen_text(50000 + i, 65536) for i in range(min(n, 10000))]
+    oz.init(0)
+    L = oz.lib()
+    dev = torch.device("cuda", 0)
+    report["zstd93_256KiB_decode"] = decode_resident(arc_z, ents_z, oz.BATCH_NO_DEFLATE)
+    report["lzfse100_brot97_64KiB_decode"] = decode_resident(arc_m, ents_m, oz.BATCH_NO_DEFLATE)
+    # encode, resident
+    nb = len(bufs)
+    ents = (N.OzgEncEntry * nb)()
+    src = bytearray()
+    off = 0
+    for i, b in enumerate(bufs):
+        ents[i].src_off = len(src)
+        src += b
+        ents[i].src_size = len(b)
+        ents[i].method = 8
+        cap = int(L.ozg_compress_bound(8, len(b)))
+        ents[i].dst_cap = cap
+        ents[i].dst_off = off
+        off += (cap + 15) & ~15
+    d_src = torch.frombuffer(src + bytearray(64), dtype=torch.uint8).to(dev)
+    d_dst = torch.empty(off + 64, dtype=torch.uint8, device=dev)
+    d_ent = torch.frombuffer(bytearray(bytes(ents)), dtype=torch.uint8).to(dev)
+    d_res = torch.zeros(nb * 16, dtype=torch.uint8, device=dev)
+    s = torch.cuda.current_stream()
+
+    def enc():
+        N.check(L.ozg_encode_batch_device(d_src.data_ptr(), d_src.numel(), d_dst.data_ptr(), d_dst.numel(),
+                                          d_ent.data_ptr(), d_res.data_ptr(), nb, s.cuda_stream))
+    t = timed(enc, steps=3)
+    res = np.frombuffer(d_res.cpu().numpy().tobytes(), dtype=np.uint32).reshape(-1, 4)
+    host = d_dst.cpu().numpy()
+    assert (res[:, 0] == 1).all()
+    for i in range(0, nb, max(1, nb // 50)):
+        assert zlib.decompress(host[ents[i].dst_off:ents[i].dst_off + res[i, 1]].tobytes(), -15) == bufs[i]
+    comp = int(res[:, 1].sum())
+    inb = sum(len(b) for b in bufs)
+    report["deflate_encode_64KiB"] = dict(ms=t * 1e3, in_GiBps=inb / t / 2**30, ratio=inb / comp,
+                                          algo_GBps=(inb + comp) / t / 1e9, frac=(inb + comp) / t / 8e12, buffers=nb)
+    # PCIe-inclusive decode through host buffers
+    tab = [(e["method"], e["data_off"], e["comp_size"], e["uncomp_size"], e["crc32"]) for e in ents_d]
+    oz.decode_batch_host(arc_d, tab)
+    t0 = time.perf_counter()
+    b = oz.decode_batch_host(arc_d, tab)
+    dt = time.perf_counter() - t0
+    assert all(b.ok(i) for i in range(len(tab)))
+    report["deflate_decode_host_buffers_pcie_inclusive"] = dict(
+        ms=dt * 1e3, out_GiBps=sum(e["uncomp_size"] for e in ents_d) / dt / 2**30, entries=len(tab),
+        note="unpinned host buffers, synchronous H2D + kernel + D2H, includes ctypes marshalling")
+    print(json.dumps(report, indent=1))
+    oz.shutdown()
+
+
+if __name__ == "__main__":
+    main()
