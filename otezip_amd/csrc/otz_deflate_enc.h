@@ -12,8 +12,9 @@
 // reference's own inflate, which rejects a final end-of-block code that starts at
 // bit 1 of the last byte, accepts every stream produced here.
 //
-// Layout: 16 KiB LDS ring of input (matches reach 14 848 bytes back), 4096-entry
-// hash head table, 2 KiB of staged output flushed with coalesced 16-byte stores.
+// Layout: 8 KiB LDS ring of input (matches reach 6 656 bytes back), 2048-entry hash
+// head table, 1 KiB of staged output flushed with coalesced 16-byte stores: 13 KB
+// per wavefront, twelve buffers in flight per CU.
 // The 64 lanes compare 64 candidate bytes per step (ballot + count-trailing-zeros
 // gives the match length) and insert the hashes of a whole match at once; token
 // selection itself is sequential per buffer -- throughput comes from the thousands
@@ -24,11 +25,11 @@
 #include "../../include/otezip_gpu.h"
 
 #define OTZ_ENC_NT 64u
-#define OTZ_ENC_WIN 16384u
+#define OTZ_ENC_WIN 8192u
 #define OTZ_ENC_WMASK (OTZ_ENC_WIN - 1u)
-#define OTZ_ENC_MAXDIST 14848u // ring 16384 - (lookahead 322 + load chunk 1024 + slack)
-#define OTZ_ENC_HASH 4096u
-#define OTZ_ENC_OUT 2048u
+#define OTZ_ENC_MAXDIST 6656u  // ring 8192 - (lookahead 322 + load chunk 1024 + slack)
+#define OTZ_ENC_HASH 2048u
+#define OTZ_ENC_OUT 1024u
 
 struct otz_enc_lds {
 	u8 win[OTZ_ENC_WIN];
@@ -47,7 +48,7 @@ struct otz_enc_state {
 };
 
 OTZ_DEV void otz_enc_flush_stage(otz_enc_lds &L, otz_enc_state &S) {
-	otz_sync ();
+	otz_wave_sync ();
 	u32 n = S.stage_fill;
 	if (S.out_pos + n > S.cap) {
 		S.overflow = true;
@@ -65,7 +66,7 @@ OTZ_DEV void otz_enc_flush_stage(otz_enc_lds &L, otz_enc_state &S) {
 	}
 	S.out_pos += n;
 	S.stage_fill = 0;
-	otz_sync ();
+	otz_wave_sync ();
 }
 
 // append nbits (<= 32) of v; every lane tracks the state, lane 0 stores
@@ -129,7 +130,7 @@ OTZ_DEV void otz_enc_put_match(otz_enc_lds &L, otz_enc_state &S, u32 len, u32 di
 }
 
 OTZ_DEV u32 otz_enc_hash(u32 b0, u32 b1, u32 b2) {
-	return (((b0 | (b1 << 8) | (b2 << 16)) * 0x9E3779B1u) >> 20) & (OTZ_ENC_HASH - 1u);
+	return (((b0 | (b1 << 8) | (b2 << 16)) * 0x9E3779B1u) >> 21) & (OTZ_ENC_HASH - 1u);
 }
 
 // Encode src[0..n) into dst (capacity cap). All 64 work-items call together and all
@@ -150,17 +151,17 @@ OTZ_DEV u32 otz_deflate_entry(otz_enc_lds &L, const u8 *src, u32 n, u8 *dst, u32
 	}
 	u32 loaded = 0, p = 0;
 	otz_enc_put (L, S, 2u, 3); // BFINAL = 0, BTYPE = 01 (fixed Huffman)
-	otz_sync ();
+	otz_wave_sync ();
 	while (p < n && !S.overflow) {
 		// keep [p - MAXDIST, p + 258 + 64) resident in the ring
 		if (loaded < n && p + 258u + 64u > loaded) {
 			u32 upto = loaded + 1024u;
-			otz_sync ();
+			otz_wave_sync ();
 			for (u32 q = loaded + lane; q < upto && q < n; q += OTZ_ENC_NT) {
 				L.win[q & OTZ_ENC_WMASK] = src[q];
 			}
 			loaded = upto < n ? upto : n;
-			otz_sync ();
+			otz_wave_sync ();
 		}
 		u32 len = 0, dist = 0;
 		u32 h = 0;
@@ -186,7 +187,7 @@ OTZ_DEV u32 otz_deflate_entry(otz_enc_lds &L, const u8 *src, u32 n, u8 *dst, u32
 				}
 			}
 		}
-		otz_sync (); // every lane has read head[] and the window
+		otz_wave_sync (); // every lane has read head[] and the window
 		if (len) {
 			otz_enc_put_match (L, S, len, dist);
 			// the whole match enters the hash table at once
@@ -205,7 +206,7 @@ OTZ_DEV u32 otz_deflate_entry(otz_enc_lds &L, const u8 *src, u32 n, u8 *dst, u32
 			}
 			p += 1u;
 		}
-		otz_sync ();
+		otz_wave_sync ();
 	}
 	otz_enc_put_litlen (L, S, 256u); // end of the fixed block
 	// final block: stored, empty (BFINAL = 1, BTYPE = 00, pad to a byte, LEN = 0, NLEN = 0xFFFF)

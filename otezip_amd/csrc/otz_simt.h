@@ -39,6 +39,12 @@ OTZ_DEV u32 otz_wave() { return threadIdx.x >> 6; }
 OTZ_DEV u32 otz_nthreads() { return blockDim.x; }
 
 OTZ_DEV void otz_sync() { __syncthreads (); }
+// For single-wavefront workgroups: LDS/global accesses of the wave issue in order, so making
+// them visible across lanes only needs the outstanding ones to drain -- no s_barrier.
+OTZ_DEV void otz_wave_sync() {
+	__builtin_amdgcn_fence (__ATOMIC_ACQ_REL, "workgroup");
+	__builtin_amdgcn_wave_barrier ();
+}
 
 // wave64 cross-lane
 OTZ_DEV u64 otz_ballot(bool p) { return __ballot (p); }

@@ -44,6 +44,7 @@ OTZ_DEV u32 otz_wave() { return otz_emu_self.tid >> 6; }
 OTZ_DEV u32 otz_nthreads() { return otz_emu_self.blk->nthreads; }
 
 OTZ_DEV void otz_sync() { pthread_barrier_wait (&otz_emu_self.blk->block_bar); }
+OTZ_DEV void otz_wave_sync() { pthread_barrier_wait (&otz_emu_self.blk->wave_bar[otz_emu_self.tid >> 6]); }
 OTZ_DEV void otz_emu_wave_sync() { pthread_barrier_wait (&otz_emu_self.blk->wave_bar[otz_wave ()]); }
 
 OTZ_DEV u64 otz_ballot(bool p) {
