@@ -62,6 +62,26 @@ def load_shard(rank, n, size, method, cache_dir):
     return arc, ent
 
 
+def pmc_traffic(entries, entry_bytes, method):
+    """HBM bytes per launch of the dominant kernel from the PMC counters.  Counters cannot be read
+    from inside this process: they come from the two separate rocprofv3 --pmc passes over this very
+    command that tools/pmc_traffic.py reduced to profiles/<round>/pmc_traffic.json (FETCH_SIZE x2
+    + WRITE_SIZE, in KiB, as the microarchitecture guide prescribes).  None when no committed
+    summary matches the workload."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json"))):
+        try:
+            with open(f) as fh:
+                j = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        w = j.get("workload", {})
+        if (w.get("entries"), w.get("entry_bytes"), w.get("method")) == (entries, entry_bytes, method):
+            best = int(j["traffic_bytes_per_launch"])
+    return best
+
+
 def cpu_baseline(arc, ent, sample_entries):
     """Reference (oracle/_ref/ref_bench, built from /root/reference in the build container)
     timed on this box's host cores over the first `sample_entries` entries of the same
@@ -201,7 +221,8 @@ def main():
                        "parallelism": "entries sharded %d-way, no data-path collective" % world,
                        "ref_false_rejects": f2},
             "roofline": {"bound": "hbm", "achieved": round(algo / kavg / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": round(algo / kavg / HBM_PEAK, 5), "traffic": None,
+                         "frac": round(algo / kavg / HBM_PEAK, 5),
+                         "traffic": pmc_traffic(n, args.entry_size, args.method),
                          "kernel": N.lib().ozg_kernel_name_inflate().decode() if args.method == 8 else
                          N.lib().ozg_kernel_name_copy().decode(),
                          "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(kavg * 1e3, 4)},
