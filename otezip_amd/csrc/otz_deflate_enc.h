@@ -12,9 +12,11 @@
 // reference's own inflate, which rejects a final end-of-block code that starts at
 // bit 1 of the last byte, accepts every stream produced here.
 //
-// Layout: 8 KiB LDS ring of input (matches reach 6 656 bytes back), 2048-entry hash
-// head table, 1 KiB of staged output flushed with coalesced 16-byte stores: 13 KB
-// per wavefront, twelve buffers in flight per CU.
+// Layout: 8 KiB LDS ring of input (matches reach 7 168 bytes back), 2048-entry hash
+// head table, 512 B of staged output flushed with coalesced 16-byte stores: 12.5 KB
+// per wavefront, a dozen buffers in flight per CU.  Measured: the token loop is
+// instruction-issue bound (~250 wave instructions per token, all lanes redundantly);
+// halving the LDS again bought 10 % speed and cost 5 % ratio, so it was not kept.
 // The 64 lanes compare 64 candidate bytes per step (ballot + count-trailing-zeros
 // gives the match length) and insert the hashes of a whole match at once; token
 // selection itself is sequential per buffer -- throughput comes from the thousands
@@ -27,9 +29,9 @@
 #define OTZ_ENC_NT 64u
 #define OTZ_ENC_WIN 8192u
 #define OTZ_ENC_WMASK (OTZ_ENC_WIN - 1u)
-#define OTZ_ENC_MAXDIST 6656u  // ring 8192 - (lookahead 322 + load chunk 1024 + slack)
+#define OTZ_ENC_MAXDIST 7168u  // ring 8192 - (lookahead 322 + load chunk 512 + slack)
 #define OTZ_ENC_HASH 2048u
-#define OTZ_ENC_OUT 1024u
+#define OTZ_ENC_OUT 512u
 
 struct otz_enc_lds {
 	u8 win[OTZ_ENC_WIN];
@@ -86,47 +88,57 @@ OTZ_DEV void otz_enc_put(otz_enc_lds &L, otz_enc_state &S, u32 v, u32 nbits) {
 	}
 }
 
-// fixed literal/length code of RFC 1951 3.2.6, bit-reversed for LSB-first packing
-OTZ_DEV void otz_enc_put_litlen(otz_enc_lds &L, otz_enc_state &S, u32 sym) {
-	u32 code, n;
+// fixed literal/length code of RFC 1951 3.2.6, bit-reversed for LSB-first packing:
+// returns the bits, *n their count (7..9)
+OTZ_DEV u32 otz_enc_litlen_bits(u32 sym, u32 *n) {
+	u32 code, k;
 	if (sym <= 143u) {
 		code = 0x30u + sym;
-		n = 8;
+		k = 8;
 	} else if (sym <= 255u) {
 		code = 0x190u + (sym - 144u);
-		n = 9;
+		k = 9;
 	} else if (sym <= 279u) {
 		code = sym - 256u;
-		n = 7;
+		k = 7;
 	} else {
 		code = 0xC0u + (sym - 280u);
-		n = 8;
+		k = 8;
 	}
-	otz_enc_put (L, S, otz_brev (code) >> (32u - n), n);
+	*n = k;
+	return otz_brev (code) >> (32u - k);
 }
 
-OTZ_DEV void otz_enc_put_match(otz_enc_lds &L, otz_enc_state &S, u32 len, u32 dist) {
+// all bits of one length/distance pair (at most 8+5+5+13 = 31), LSB first
+OTZ_DEV u32 otz_enc_match_bits(u32 len, u32 dist, u32 *n) {
+	u32 bits, k;
 	if (len == 258u) {
-		otz_enc_put_litlen (L, S, 285u);
+		bits = otz_enc_litlen_bits (285u, &k);
 	} else {
 		u32 l = len - 3u;
 		if (l < 8u) {
-			otz_enc_put_litlen (L, S, 257u + l);
+			bits = otz_enc_litlen_bits (257u + l, &k);
 		} else {
 			u32 hb = 31u - (u32)__builtin_clz (l), xb = hb - 2u;
-			otz_enc_put_litlen (L, S, 257u + 4u * hb - 4u + ((l >> xb) & 3u));
-			otz_enc_put (L, S, l & ((1u << xb) - 1u), xb);
+			bits = otz_enc_litlen_bits (257u + 4u * hb - 4u + ((l >> xb) & 3u), &k);
+			bits |= (l & ((1u << xb) - 1u)) << k;
+			k += xb;
 		}
 	}
 	u32 d = dist - 1u;
 	if (d < 4u) {
-		otz_enc_put (L, S, otz_brev (d) >> 27, 5);
+		bits |= (otz_brev (d) >> 27) << k;
+		k += 5u;
 	} else {
 		u32 hb = 31u - (u32)__builtin_clz (d), xb = hb - 1u;
 		u32 code = 2u * hb + ((d >> xb) & 1u);
-		otz_enc_put (L, S, otz_brev (code) >> 27, 5);
-		otz_enc_put (L, S, d & ((1u << xb) - 1u), xb);
+		bits |= (otz_brev (code) >> 27) << k;
+		k += 5u;
+		bits |= (d & ((1u << xb) - 1u)) << k;
+		k += xb;
 	}
+	*n = k;
+	return bits;
 }
 
 OTZ_DEV u32 otz_enc_hash(u32 b0, u32 b1, u32 b2) {
@@ -155,7 +167,7 @@ OTZ_DEV u32 otz_deflate_entry(otz_enc_lds &L, const u8 *src, u32 n, u8 *dst, u32
 	while (p < n && !S.overflow) {
 		// keep [p - MAXDIST, p + 258 + 64) resident in the ring
 		if (loaded < n && p + 258u + 64u > loaded) {
-			u32 upto = loaded + 1024u;
+			u32 upto = loaded + 512u;
 			otz_wave_sync ();
 			for (u32 q = loaded + lane; q < upto && q < n; q += OTZ_ENC_NT) {
 				L.win[q & OTZ_ENC_WMASK] = src[q];
@@ -188,8 +200,9 @@ OTZ_DEV u32 otz_deflate_entry(otz_enc_lds &L, const u8 *src, u32 n, u8 *dst, u32
 			}
 		}
 		otz_wave_sync (); // every lane has read head[] and the window
+		u32 tb, tn;
 		if (len) {
-			otz_enc_put_match (L, S, len, dist);
+			tb = otz_enc_match_bits (len, dist, &tn);
 			// the whole match enters the hash table at once
 			for (u32 j = lane; j < len; j += OTZ_ENC_NT) {
 				u32 q = p + j;
@@ -200,15 +213,20 @@ OTZ_DEV u32 otz_deflate_entry(otz_enc_lds &L, const u8 *src, u32 n, u8 *dst, u32
 			}
 			p += len;
 		} else {
-			otz_enc_put_litlen (L, S, L.win[p & OTZ_ENC_WMASK]);
+			tb = otz_enc_litlen_bits (L.win[p & OTZ_ENC_WMASK], &tn);
 			if (can_hash && lane == 0) {
 				L.head[h] = (u16)p;
 			}
 			p += 1u;
 		}
+		otz_enc_put (L, S, tb, tn); // the one place the token loop emits bits
 		otz_wave_sync ();
 	}
-	otz_enc_put_litlen (L, S, 256u); // end of the fixed block
+	{
+		u32 n7;
+		u32 eob = otz_enc_litlen_bits (256u, &n7); // end of the fixed block
+		otz_enc_put (L, S, eob, n7);
+	}
 	// final block: stored, empty (BFINAL = 1, BTYPE = 00, pad to a byte, LEN = 0, NLEN = 0xFFFF)
 	otz_enc_put (L, S, 1u, 3);
 	if (S.nacc & 7u) {
