@@ -777,3 +777,153 @@ done:
 	}
 	return rc;
 }
+
+/* -------------------------------------------------------------- encode side */
+
+uint64_t otz_compress_bound(uint16_t method, uint64_t n) {
+	switch (method) {
+	case OTZ_M_DEFLATE: return n + (n >> 3) + 64u + 11u; /* ref deflate.inc.c:72-77 */
+	case OTZ_M_ZSTD: return n + 1024u;                   /* ref otezip.c:860 */
+	case OTZ_M_LZFSE: return n + n / 10u + 100u;         /* :931 */
+	case OTZ_M_LZMA: return n + 13u + n / 8u;            /* :975 */
+	case OTZ_M_BROTLI: return 2u * n + 64u;              /* :1019 */
+	case OTZ_M_STORE: return n;
+	default: return 0;
+	}
+}
+
+/* ref zstd.inc.c:254-414 driven by the loop at otezip.c:878-881 */
+uint64_t otz_zstd_encode(const uint8_t *in, uint64_t n, uint8_t *out, uint64_t cap) {
+	uint64_t op = 0, ip = 0;
+	if (cap < 5) {
+		return 0;
+	}
+	static const uint8_t hdr[5] = { 0xFD, 0x2F, 0xB5, 0x28, 0x70 };
+	memcpy (out, hdr, 5);
+	op = 5;
+	while (ip < n) {
+		uint64_t bs = n - ip < 65535u ? n - ip : 65535u;
+		if (cap - op < 3 || cap - op - 3 < bs) {
+			return 0; /* Z_BUF_ERROR: the driver falls back to STORE */
+		}
+		out[op++] = 0x00;
+		out[op++] = (uint8_t)bs;
+		out[op++] = (uint8_t) (bs >> 8);
+		memcpy (out + op, in + ip, bs);
+		op += bs;
+		ip += bs;
+	}
+	if (cap - op < 3) {
+		return 0;
+	}
+	out[op++] = 0x01;
+	out[op++] = 0;
+	out[op++] = 0;
+	return op;
+}
+
+/* ref lzfse.inc.c:179-219 */
+uint64_t otz_lzfse_encode(const uint8_t *in, uint64_t n, uint8_t *out, uint64_t cap) {
+	if (n + 5 > cap) {
+		return 0;
+	}
+	out[0] = 0x06;
+	out[1] = (uint8_t)n;
+	out[2] = (uint8_t) (n >> 8);
+	out[3] = (uint8_t) (n >> 16);
+	out[4] = (uint8_t) (n >> 24);
+	memcpy (out + 5, in, n);
+	return n + 5;
+}
+
+/* ref brotli.inc.c:41-55 */
+uint64_t otz_brotli_encode(const uint8_t *in, uint64_t n, uint8_t *out, uint64_t cap) {
+	if (cap < 17 || n > cap - 17) {
+		return 0;
+	}
+	memcpy (out, "BROT", 4);
+	out[4] = 1;
+	for (int i = 0; i < 8; i++) {
+		out[5 + i] = (uint8_t) (n >> (8 * i));
+	}
+	uint32_t c = otz_crc32 (0, in, n);
+	for (int i = 0; i < 4; i++) {
+		out[13 + i] = (uint8_t) (c >> (8 * i));
+	}
+	memcpy (out + 17, in, n);
+	return n + 17;
+}
+
+/* ref lzma-enc.inc.c:110-161 (token writer) inside lzmaCompress :220-300 (13-byte header, 64 KiB
+ * chunks, the "chunk + 32 bytes must still fit" test before every chunk). Returns 0 where the
+ * reference returns an error (the driver then stores the entry, otezip.c:992-1001). */
+uint64_t otz_lzma_encode(const uint8_t *in, uint64_t n, uint8_t *out, uint64_t cap) {
+	if (cap < 13) {
+		return 0;
+	}
+	static const uint8_t props[5] = { 0x5D, 0x00, 0x00, 0x00, 0x01 };
+	memcpy (out, props, 5);
+	for (int i = 0; i < 8; i++) {
+		out[5 + i] = (uint8_t) (n >> (8 * i));
+	}
+	uint64_t op = 13, ip = 0;
+	while (ip < n) {
+		uint64_t chunk = n - ip < 65536u ? n - ip : 65536u;
+		if (cap - op < chunk + 32u) {
+			return 0; /* Z_BUF_ERROR, ref :277-280 */
+		}
+		/* tokens of this chunk: runs of one byte, at most 255 long, never across chunks */
+		uint64_t sp = 0;
+		uint64_t start = op;
+		while (sp < chunk) {
+			uint8_t b = in[ip + sp];
+			uint64_t run = 1;
+			while (sp + run < chunk && in[ip + sp + run] == b && run < 255) {
+				run++;
+			}
+			uint64_t need = run >= 4 ? 3 : 2 + run;
+			if (cap - op < need) {
+				return 0; /* compressed_size > avail_out, ref :288-290 */
+			}
+			if (run >= 4) {
+				out[op++] = 0x00;
+				out[op++] = b;
+				out[op++] = (uint8_t)run;
+			} else {
+				out[op++] = 0x01;
+				out[op++] = (uint8_t)run;
+				memset (out + op, b, run);
+				op += run;
+			}
+			sp += run;
+		}
+		(void)start;
+		ip += chunk;
+	}
+	return op;
+}
+
+/* otezip_compress_data for the byte-adding/private methods (ref otezip.c:855-1071): the
+ * payload the reference writes and the method it ends up with.  Returns the payload size and
+ * sets *method_out; DEFLATE is not covered (its reference bytes are invalid). */
+uint64_t otz_compress_data_private(uint16_t method, const uint8_t *in, uint64_t n, uint8_t *out, uint16_t *method_out) {
+	uint64_t sz = 0;
+	*method_out = OTZ_M_STORE;
+	if (n == 0) {
+		return 0; /* ref :793-801 */
+	}
+	uint64_t cap = otz_compress_bound (method, n);
+	switch (method) {
+	case OTZ_M_ZSTD: sz = otz_zstd_encode (in, n, out, cap); break;
+	case OTZ_M_LZFSE: sz = otz_lzfse_encode (in, n, out, cap); break;
+	case OTZ_M_BROTLI: sz = otz_brotli_encode (in, n, out, cap); break;
+	case OTZ_M_LZMA: sz = otz_lzma_encode (in, n, out, cap); break;
+	default: sz = 0; break;
+	}
+	if (sz == 0 || sz >= n) {
+		memcpy (out, in, n); /* "not smaller -> STORE", ref :894-899 and siblings */
+		return n;
+	}
+	*method_out = method;
+	return sz;
+}

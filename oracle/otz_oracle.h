@@ -111,12 +111,15 @@ uint64_t otz_brotli_encode(const uint8_t *in, uint64_t in_len, uint8_t *out, uin
 /* ref: src/lib/lzma-enc.inc.c:110-161, :166-322 */
 uint64_t otz_lzma_encode(const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t out_cap);
 
-/* Size (only) of what the reference's DEFLATE encoder emits for this buffer
- * at its default level; the bytes themselves are not valid DEFLATE (SURVEY
- * F3), so only total_out is a meaningful observable (parity rule 5).
- * ref: src/lib/deflate-enc.inc.c:262-525.  Returns 0 when the reference
- * encoder fails (Z_BUF_ERROR etc.). */
-uint64_t otz_deflate_ref_size(const uint8_t *in, uint64_t in_len);
+/* otezip_compress_data for methods 93/100/97/14 (ref src/lib/otezip.c:855-1071): payload bytes
+ * the reference writes and the method it ends up with after its "not smaller -> STORE" rule.
+ * out must hold max(n, otz_compress_bound(method, n)) bytes. Returns the payload size. */
+uint64_t otz_compress_data_private(uint16_t method, const uint8_t *in, uint64_t n, uint8_t *out, uint16_t *method_out);
+
+/* The reference's DEFLATE encoder emits undecodable bytes; only its output SIZE is
+ * comparable (parity rule 5).  Those sizes are taken from the reference build itself and
+ * committed as fixtures (tests/golden/entries.json "ref_deflate_sizes"); the encoder is not
+ * restated here. */
 
 #ifdef __cplusplus
 }

@@ -62,11 +62,52 @@ def lib():
         if hasattr(L, "otz_compress_bound"):
             L.otz_compress_bound.restype = C.c_uint64
             L.otz_compress_bound.argtypes = [C.c_uint16, C.c_uint64]
-        if hasattr(L, "otz_deflate_ref_size"):
-            L.otz_deflate_ref_size.restype = C.c_uint64
-            L.otz_deflate_ref_size.argtypes = [C.c_char_p, C.c_uint64]
+        L.otz_compress_data_private.restype = C.c_uint64
+        L.otz_compress_data_private.argtypes = [C.c_uint16, C.c_char_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint16)]
         _lib = L
     return _lib
+
+
+def compress_data_private(method, data):
+    """Oracle of otezip_compress_data for methods 93/100/97/14 -> (method_written, payload)."""
+    data = bytes(data)
+    cap = max(len(data), int(lib().otz_compress_bound(method, len(data)))) + 16
+    out = C.create_string_buffer(cap)
+    m = C.c_uint16(0)
+    n = lib().otz_compress_data_private(method, data, len(data), out, C.byref(m))
+    return m.value, out.raw[:n]
+
+
+def ref_compress_data(method, data):
+    """What the reference's zip_file_add writes for one buffer: (method, payload), read back from
+    an archive it created (default_method poked the way its CLI does, src/main.c:190)."""
+    import zipfile
+    R = ref()
+
+    class Zip(C.Structure):
+        _fields_ = [("fp", C.c_void_p), ("entries", C.c_void_p), ("n_entries", C.c_uint64), ("mode", C.c_int),
+                    ("next_index", C.c_uint64), ("default_method", C.c_uint16)]
+    R.zip_open.restype = C.POINTER(Zip)
+    R.zip_source_buffer.restype = C.c_void_p
+    R.zip_source_buffer.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_int]
+    R.zip_file_add.restype = C.c_int64
+    R.zip_file_add.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int]
+    R.zip_close.argtypes = [C.c_void_p]
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "w.zip")
+        err = C.c_int(0)
+        za = R.zip_open(path.encode(), 1 | 8, C.byref(err))
+        za.contents.default_method = method
+        data = bytes(data)
+        keep = C.create_string_buffer(data, max(len(data), 1))
+        src = R.zip_source_buffer(za, keep, len(data), 0)
+        assert R.zip_file_add(za, b"e", src, 0) == 0
+        R.zip_close(za)
+        R.zip_open.restype = C.c_void_p
+        raw = open(path, "rb").read()
+    m, csize = struct.unpack_from("<H", raw, 8)[0], struct.unpack_from("<I", raw, 18)[0]
+    nlen = struct.unpack_from("<H", raw, 26)[0]
+    return m, raw[30 + nlen:30 + nlen + csize]
 
 
 def crc32(data, crc=0):

@@ -249,11 +249,138 @@ OTZ_DEV u32 otz_deflate_entry(otz_enc_lds &L, const u8 *src, u32 n, u8 *dst, u32
 	return S.overflow ? ~0u : S.out_pos;
 }
 
+// ---------------------------------------------------------------- method 14
+// The reference's private "lzma" token writer (ref src/lib/lzma-enc.inc.c:110-161 inside
+// lzmaCompress :220-300): 13-byte header (5D 00 00 00 01 + LE64 size), then per 64 KiB chunk
+// runs of one byte, at most 255 long: run >= 4 -> 00 <byte> <n>; shorter -> 01 <n> <byte x n>.
+// Byte-exact.  One wavefront: 64 input bytes per step, run starts from a ballot, token offsets
+// from a wave prefix sum; a run that crosses steps is carried.  Returns the size, or ~0u where
+// the reference fails or can no longer end up smaller than the input (both mean STORE).
+
+OTZ_DEV u32 otz_lzma_emit_run(u8 *out, u32 op, u32 cap, u32 byte, u32 len, bool *overflow) {
+	// uniform; lane 0 stores.  A carried run may exceed 255: the reference cuts and restarts.
+	while (len > 0) {
+		u32 r = len < 255u ? len : 255u;
+		u32 need = r >= 4u ? 3u : 2u + r;
+		if (cap - op < need) {
+			*overflow = true;
+			return op;
+		}
+		if (otz_tid () == 0) {
+			if (r >= 4u) {
+				out[op] = 0x00;
+				out[op + 1] = (u8)byte;
+				out[op + 2] = (u8)r;
+			} else {
+				out[op] = 0x01;
+				out[op + 1] = (u8)r;
+				for (u32 k = 0; k < r; k++) {
+					out[op + 2 + k] = (u8)byte;
+				}
+			}
+		}
+		op += need;
+		len -= r;
+	}
+	return op;
+}
+
+OTZ_DEV u32 otz_lzma_tok_entry(const u8 *in, u32 n, u8 *out, u32 cap) {
+	const u32 lane = otz_tid ();
+	if (cap < 13u) {
+		return ~0u;
+	}
+	if (lane < 13u) {
+		const u8 props[5] = { 0x5D, 0x00, 0x00, 0x00, 0x01 };
+		out[lane] = lane < 5u ? props[lane] : (lane < 9u ? (u8) (n >> (8u * (lane - 5u))) : (u8)0);
+	}
+	u32 op = 13, ip = 0;
+	bool overflow = false;
+	while (ip < n) {
+		u32 chunk = n - ip < 65536u ? n - ip : 65536u;
+		if (cap - op < chunk + 32u) {
+			return ~0u; // Z_BUF_ERROR, ref :277-280
+		}
+		u32 carry_len = 0, carry_byte = 0;
+		for (u32 base = 0; base < chunk; base += 64u) {
+			u32 idx = base + lane;
+			bool valid = idx < chunk;
+			u32 b = valid ? in[ip + idx] : 0u;
+			u32 prev = otz_shfl_up (b, 1);
+			bool same = lane == 0 ? (carry_len > 0 && b == carry_byte) : (b == prev);
+			u64 V = otz_ballot (valid);
+			u64 B = otz_ballot (valid && !same); // a run starts at this lane
+			u32 nvalid = otz_popc64 (V);
+			u32 first = B ? (u32)__builtin_ctzll (B) : nvalid;
+			carry_len += first;
+			if (B) {
+				op = otz_lzma_emit_run (out, op, cap, carry_byte, carry_len, &overflow);
+				carry_len = 0;
+			} else {
+				while (carry_len >= 255u && !overflow) {
+					op = otz_lzma_emit_run (out, op, cap, carry_byte, 255u, &overflow);
+					carry_len -= 255u;
+				}
+			}
+			// runs that start AND end inside this step; the last start becomes the carry
+			u64 above = lane < 63u ? (B >> (lane + 1u)) : 0ull;
+			bool starts = (B >> lane) & 1ull;
+			bool complete = starts && above != 0;
+			u32 len = complete ? (u32)__builtin_ctzll (above) + 1u : 0u;
+			u32 tsz = complete ? (len >= 4u ? 3u : 2u + len) : 0u;
+			u32 incl = tsz;
+#pragma unroll
+			for (u32 d = 1; d < 64; d <<= 1) {
+				u32 o = otz_shfl_up (incl, d);
+				if (lane >= d) {
+					incl += o;
+				}
+			}
+			u32 total = otz_shfl (incl, 63);
+			if (cap - op < total) {
+				overflow = true;
+			}
+			if (overflow) {
+				return ~0u; // compressed_size > avail_out, ref :288-290
+			}
+			if (complete) {
+				u32 at = op + incl - tsz;
+				if (len >= 4u) {
+					out[at] = 0x00;
+					out[at + 1] = (u8)b;
+					out[at + 2] = (u8)len;
+				} else {
+					out[at] = 0x01;
+					out[at + 1] = (u8)len;
+					for (u32 k = 0; k < len; k++) {
+						out[at + 2 + k] = (u8)b;
+					}
+				}
+			}
+			op += total;
+			if (B) {
+				u32 last = 63u - (u32)__builtin_clzll (B);
+				carry_byte = otz_shfl (b, last);
+				carry_len = nvalid - last;
+			}
+			if (op >= n) {
+				return ~0u; // can no longer be smaller than the input: STORE (ref otezip.c:1006-1011)
+			}
+		}
+		op = otz_lzma_emit_run (out, op, cap, carry_byte, carry_len, &overflow); // runs never cross chunks
+		if (overflow) {
+			return ~0u;
+		}
+		ip += chunk;
+	}
+	return op;
+}
+
 // One buffer of an encode batch: otezip_compress_data (ref src/lib/otezip.c:788-1076) for it.
 //  * method 8: DEFLATE as above; "not smaller than the input" or "does not fit" -> STORE (:846-850)
 //  * methods 93 / 100 / 97: the reference's writers only add bytes to the input,
 //    so its own fallback rule always stores such entries; STORE is written directly
-//  * method 14 (private RLE tokens, ref lzma-enc.inc.c:110-161): not encoded here yet -> STORE
+//  * method 14: the private RLE tokens above, byte-exact, same fallback rule (:1006-1011)
 //  * zero-length input -> STORE with size 0 (:793-801)
 // The CRC-32 of the input (ref :1124) is taken by otz_enc_crc_kernel.
 OTZ_DEV void otz_encode_entry(otz_enc_lds &L, const u8 *src, u8 *dst, const ozg_enc_entry &e, ozg_enc_result *res) {
@@ -278,6 +405,17 @@ OTZ_DEV void otz_encode_entry(otz_enc_lds &L, const u8 *src, u8 *dst, const ozg_
 			res->comp_size = cs;
 		}
 	}
+	if (e.method == OZG_METHOD_LZMA && e.src_size > 0) {
+		// the reference's own buffer size decides where its writer gives up (ref otezip.c:975)
+		u32 ref_cap = e.src_size + 13u + e.src_size / 8u;
+		u32 cs = e.dst_cap >= ref_cap ? otz_lzma_tok_entry (in, e.src_size, out, ref_cap) : ~0u;
+		stored = cs >= e.src_size;
+		otz_wave_sync ();
+		if (!stored && lane == 0) {
+			res->status = OZG_ST_OK;
+			res->comp_size = cs;
+		}
+	}
 	if (stored) {
 		u32 n = e.src_size;
 		for (u32 c = lane; c < (n >> 4); c += OTZ_ENC_NT) {
@@ -292,7 +430,7 @@ OTZ_DEV void otz_encode_entry(otz_enc_lds &L, const u8 *src, u8 *dst, const ozg_
 		}
 	}
 	if (lane == 0) {
-		res->method = stored ? (uint16_t)OZG_METHOD_STORE : (uint16_t)OZG_METHOD_DEFLATE;
+		res->method = stored ? (uint16_t)OZG_METHOD_STORE : e.method;
 		res->flags = 0;
 	}
 }

@@ -84,3 +84,49 @@ def test_gpu_config5_shape(gpu_lib):
         assert method == 8 and zlib.decompress(payload, -15) == b and crc == zlib.crc32(b) & 0xFFFFFFFF
         total += len(payload)
     assert 500 * 65536 / total > 1.5
+
+
+def _private_cases():
+    import random
+    r = random.Random(77)
+
+    def runs(nb, maxrun):
+        out = bytearray()
+        while len(out) < nb:
+            out += bytes([r.randrange(4) + 65]) * r.randint(1, maxrun)
+        return bytes(out[:nb])
+    return [b"a", b"aaaa", b"aaa", b"ab" * 50, runs(100, 3), runs(100, 10), runs(5000, 600), b"x" * 256,
+            b"x" * 255 + b"y", b"x" * 300, runs(31, 20), runs(255, 20), runs(257, 20), corpus.gen_text(5, 700),
+            runs(70000, 40), runs(140000, 300)]
+
+
+def test_private_writers_are_byte_exact_under_emulation():
+    """Methods 93/100/97/14 through the kernel body vs the oracle's restatement of
+    otezip_compress_data (which tests/test_oracle_vs_ref.py pins to the reference's zip_file_add)."""
+    cases = [c for c in _private_cases() if len(c) <= 5000]
+    for m in (14, 93):
+        out = emu_encode(cases, method=m)
+        for b, (r, payload) in zip(cases, out):
+            om, op = O.compress_data_private(m, b)
+            assert r.status == 1 and (r.method, payload) == (om, op), (m, len(b), r.method, om)
+    assert any(O.compress_data_private(14, c)[0] == 14 for c in cases)   # some really are written as method 14
+
+
+@pytest.mark.gpu
+def test_gpu_private_writers_are_byte_exact(gpu_lib):
+    cases = _private_cases()
+    for m in (14, 93, 100, 97, 0):
+        out = gpu_lib.encode_batch_host(cases, m)
+        for b, (method, payload, crc) in zip(cases, out):
+            om, op = O.compress_data_private(m, b) if m else (0, b)
+            assert (method, payload) == (om, op), (m, len(b), method, om, len(payload), len(op))
+            assert crc == zlib.crc32(b) & 0xFFFFFFFF
+    # what the GPU wrote as method 14 decodes on the GPU too (entries <= 64 KiB, SURVEY F8)
+    small = [c for c in cases if len(c) <= 65536]
+    out = gpu_lib.encode_batch_host(small, 14)
+    items, blob = [], bytearray()
+    for b, (method, payload, crc) in zip(small, out):
+        items.append((method, len(blob), len(payload), len(b), crc))
+        blob += payload
+    dec = gpu_lib.decode_batch_host(bytes(blob) + b"\0" * 16, items)
+    assert all(dec.ok(i) and dec.data(i) == b for i, b in enumerate(small))

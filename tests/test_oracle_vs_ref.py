@@ -62,3 +62,12 @@ def test_extract_entry_matches_zip_fopen_index():
             assert (o["rc"] == 0) == (r is not None), (method, len(comp), usize, strict)
             if r is not None:
                 assert r == o["out"]
+
+
+def test_private_writers_match_reference_zip_file_add():
+    """otezip_compress_data for methods 93/100/97/14 (incl. the "not smaller -> STORE" rule and the
+    chunk-space checks of the LZMA-token writer) against archives the reference itself writes."""
+    import test_encode
+    for m in (93, 100, 97, 14):
+        for d in [b""] + test_encode._private_cases():
+            assert O.compress_data_private(m, d) == O.ref_compress_data(m, d), (m, len(d))
