@@ -132,6 +132,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cache-dir", default=os.environ.get("OTEZIP_BENCH_CACHE", "/tmp/otezip_amd_cache"))
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo to rehearse N>1 on one GPU")
+    ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     args = ap.parse_args()
 
     from otezip_amd import dist as D
@@ -148,10 +150,12 @@ def main():
     arc, ent = load_shard(rank, args.entries, args.entry_size, args.method, args.cache_dir)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: otezip-amd has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    D.init("nccl", dev)
-    oz.init(local_rank)
+    dev_index = 0 if args.share_device else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    D.init(args.dist_backend, dev)
+    red_dev = dev if args.dist_backend == "nccl" else "cpu"  # where the scalar reductions live
+    oz.init(dev_index)
     L = oz.lib()
 
     n = len(ent)
@@ -185,7 +189,7 @@ def main():
     torch.cuda.synchronize()
     D.barrier()
     torch.cuda.synchronize()
-    elapsed = D.reduce_max(time.perf_counter() - t0, dev)
+    elapsed = D.reduce_max(time.perf_counter() - t0, red_dev)
     kernel_ms = [a.elapsed_time(b) for a, b in evs]
 
     # every entry must have decoded and must match the directory CRC
@@ -205,7 +209,7 @@ def main():
         raise SystemExit("[bench] INVALID RUN: %d entries failed, %d CRC mismatches, %d byte mismatches" %
                          (bad, crc_bad, mism))
 
-    total_out = D.reduce_sum(out_bytes, dev)  # whole job: every rank's shard
+    total_out = D.reduce_sum(out_bytes, red_dev)  # whole job: every rank's shard
     if rank == 0:
         value = total_out * args.steps / elapsed / 2**30
         kavg = sum(kernel_ms) / len(kernel_ms) * 1e-3
