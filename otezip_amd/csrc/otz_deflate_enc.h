@@ -13,14 +13,11 @@
 // bit 1 of the last byte, accepts every stream produced here.
 //
 // Layout: 8 KiB LDS ring of input (matches reach 7 168 bytes back), 2048-entry hash
-// head table, 512 B of staged output flushed with coalesced 16-byte stores: 12.5 KB
-// per wavefront, a dozen buffers in flight per CU.  Measured: the token loop is
-// instruction-issue bound (~250 wave instructions per token, all lanes redundantly);
-// halving the LDS again bought 10 % speed and cost 5 % ratio, so it was not kept.
-// The 64 lanes compare 64 candidate bytes per step (ballot + count-trailing-zeros
-// gives the match length) and insert the hashes of a whole match at once; token
-// selection itself is sequential per buffer -- throughput comes from the thousands
-// of buffers a batch holds.
+// head table, 2 KiB bit buffer drained with coalesced 16-byte stores: 14 KB per
+// wavefront, eleven buffers in flight per CU.
+// The 64 lanes work on 64 consecutive input positions per step (one hash probe and
+// one match measurement each); only the choice of the greedy token chain through
+// those 64 positions is serial, and it is a register walk.
 #pragma once
 
 #include "otz_simt.h"
@@ -31,60 +28,51 @@
 #define OTZ_ENC_WMASK (OTZ_ENC_WIN - 1u)
 #define OTZ_ENC_MAXDIST 7168u  // ring 8192 - (lookahead 322 + load chunk 512 + slack)
 #define OTZ_ENC_HASH 2048u
-#define OTZ_ENC_OUT 512u
+#define OTZ_ENC_OUT 2048u      // bit buffer: drained by halves, a step adds at most 64 * 31 bits
 
 struct otz_enc_lds {
 	u8 win[OTZ_ENC_WIN];
 	u16 head[OTZ_ENC_HASH];
-	u32 out_w[OTZ_ENC_OUT / 4];
+	u32 out_w[OTZ_ENC_OUT / 4]; // bit buffer: tokens are OR-ed in at their bit offsets
 };
 
 struct otz_enc_state {
-	u64 acc;        // pending output bits, LSB first
-	u32 nacc;
-	u32 stage_fill; // bytes staged in L.out_w
-	u32 out_pos;    // bytes already in global memory
+	u32 bitpos;  // bits pending in L.out_w
+	u32 out_pos; // bytes already in global memory (a multiple of OTZ_ENC_OUT / 2)
 	u32 cap;
 	u8 *dst;
 	bool overflow;
 };
 
-OTZ_DEV void otz_enc_flush_stage(otz_enc_lds &L, otz_enc_state &S) {
-	otz_wave_sync ();
-	u32 n = S.stage_fill;
-	if (S.out_pos + n > S.cap) {
-		S.overflow = true;
-		n = 0;
+// OR nbits (<= 32) of v into the bit buffer at bit offset `off`
+OTZ_DEV void otz_enc_or_bits(otz_enc_lds &L, u32 off, u32 v, u32 nbits) {
+	u32 w = off >> 5, sh = off & 31u;
+	otz_lds_or (&L.out_w[w], v << sh);
+	if (sh + nbits > 32u) {
+		otz_lds_or (&L.out_w[w + 1u], v >> (32u - sh));
 	}
-	const u8 *src = reinterpret_cast<const u8 *> (L.out_w);
-	if ((n & 15u) == 0) {
-		for (u32 c = otz_tid (); c < (n >> 4); c += OTZ_ENC_NT) {
-			otz_st16_aligned (S.dst + S.out_pos + 16u * c, *reinterpret_cast<const otz_u4 *> (src + 16u * c));
-		}
-	} else {
-		for (u32 i = otz_tid (); i < n; i += OTZ_ENC_NT) {
-			S.dst[S.out_pos + i] = src[i];
-		}
-	}
-	S.out_pos += n;
-	S.stage_fill = 0;
-	otz_wave_sync ();
 }
 
-// append nbits (<= 32) of v; every lane tracks the state, lane 0 stores
-OTZ_DEV void otz_enc_put(otz_enc_lds &L, otz_enc_state &S, u32 v, u32 nbits) {
-	S.acc |= (u64)v << S.nacc;
-	S.nacc += nbits;
-	if (S.nacc >= 32u) {
-		if (otz_tid () == 0) {
-			L.out_w[S.stage_fill >> 2] = (u32)S.acc;
+// Move the first half of the bit buffer (OTZ_ENC_OUT / 2 bytes) to global memory once it is full.
+OTZ_DEV void otz_enc_drain(otz_enc_lds &L, otz_enc_state &S) {
+	const u32 HALF_W = OTZ_ENC_OUT / 8, HALF_B = OTZ_ENC_OUT / 2;
+	while (S.bitpos >= HALF_B * 8u) {
+		otz_wave_sync ();
+		if (S.out_pos + HALF_B > S.cap) {
+			S.overflow = true;
+		} else {
+			for (u32 c = otz_tid (); c < HALF_B / 16u; c += OTZ_ENC_NT) {
+				otz_st16_aligned (S.dst + S.out_pos + 16u * c, *reinterpret_cast<const otz_u4 *> (&L.out_w[4u * c]));
+			}
 		}
-		S.acc >>= 32;
-		S.nacc -= 32u;
-		S.stage_fill += 4u;
-		if (S.stage_fill == OTZ_ENC_OUT) {
-			otz_enc_flush_stage (L, S);
+		otz_wave_sync ();
+		for (u32 i = otz_tid (); i < HALF_W; i += OTZ_ENC_NT) {
+			L.out_w[i] = L.out_w[i + HALF_W];
+			L.out_w[i + HALF_W] = 0;
 		}
+		otz_wave_sync ();
+		S.out_pos += HALF_B;
+		S.bitpos -= HALF_B * 8u;
 	}
 }
 
@@ -148,12 +136,17 @@ OTZ_DEV u32 otz_enc_hash(u32 b0, u32 b1, u32 b2) {
 // Encode src[0..n) into dst (capacity cap). All 64 work-items call together and all
 // get the compressed size, or ~0u when the output does not fit (the caller then
 // stores the entry, ref otezip.c:846-850).
+//
+// 64 input positions per step, one per lane: every lane hashes its three bytes, reads the
+// hash head (the previous occurrence), all lanes then publish their own position, and each
+// measures its match.  The greedy token chain through the 64 positions is picked by a short
+// uniform walk (readlane of each step's advance); the chosen lanes build their code bits, a
+// wave prefix sum gives every token its bit offset and the tokens are OR-ed into the LDS bit
+// buffer in parallel.
 OTZ_DEV u32 otz_deflate_entry(otz_enc_lds &L, const u8 *src, u32 n, u8 *dst, u32 cap) {
 	const u32 lane = otz_tid ();
 	otz_enc_state S;
-	S.acc = 0;
-	S.nacc = 0;
-	S.stage_fill = 0;
+	S.bitpos = 3; // BFINAL = 0, BTYPE = 01 (fixed Huffman): bits 0 1 0, LSB first
 	S.out_pos = 0;
 	S.cap = cap;
 	S.dst = dst;
@@ -161,92 +154,105 @@ OTZ_DEV u32 otz_deflate_entry(otz_enc_lds &L, const u8 *src, u32 n, u8 *dst, u32
 	for (u32 i = lane; i < OTZ_ENC_HASH; i += OTZ_ENC_NT) {
 		L.head[i] = 0;
 	}
-	u32 loaded = 0, p = 0;
-	otz_enc_put (L, S, 2u, 3); // BFINAL = 0, BTYPE = 01 (fixed Huffman)
+	for (u32 i = lane; i < OTZ_ENC_OUT / 4; i += OTZ_ENC_NT) {
+		L.out_w[i] = i == 0 ? 2u : 0u;
+	}
+	u32 loaded = 0, skip = 0;
 	otz_wave_sync ();
-	while (p < n && !S.overflow) {
-		// keep [p - MAXDIST, p + 258 + 64) resident in the ring
-		if (loaded < n && p + 258u + 64u > loaded) {
+	for (u32 p = 0; p < n && !S.overflow; p += 64u) {
+		// keep [p - MAXDIST, p + 64 + 258 + 3) resident in the ring
+		while (loaded < n && p + 64u + 258u + 3u > loaded) {
 			u32 upto = loaded + 512u;
-			otz_wave_sync ();
 			for (u32 q = loaded + lane; q < upto && q < n; q += OTZ_ENC_NT) {
 				L.win[q & OTZ_ENC_WMASK] = src[q];
 			}
 			loaded = upto < n ? upto : n;
-			otz_wave_sync ();
 		}
-		u32 len = 0, dist = 0;
-		u32 h = 0;
-		const bool can_hash = p + 3u <= n;
-		if (can_hash) {
-			h = otz_enc_hash (L.win[p & OTZ_ENC_WMASK], L.win[(p + 1u) & OTZ_ENC_WMASK], L.win[(p + 2u) & OTZ_ENC_WMASK]);
-			dist = (p - (u32)L.head[h]) & 0xFFFFu;
-			if (dist >= 1u && dist <= OTZ_ENC_MAXDIST && dist <= p) {
-				u32 maxlen = n - p < 258u ? n - p : 258u;
-				len = maxlen;
-				for (u32 k = 0; k < 320u; k += 64u) {
-					u32 idx = k + lane;
-					bool same = idx < maxlen && L.win[(p + idx) & OTZ_ENC_WMASK] == L.win[(p - dist + idx) & OTZ_ENC_WMASK];
-					u64 diff = otz_ballot (!same);
-					if (diff) {
-						u32 first = (u32)__builtin_ctzll (diff);
-						len = k + first < maxlen ? k + first : maxlen;
-						break;
-					}
-				}
-				if (len < 3u) {
-					len = 0;
-				}
-			}
-		}
-		otz_wave_sync (); // every lane has read head[] and the window
-		u32 tb, tn;
-		if (len) {
-			tb = otz_enc_match_bits (len, dist, &tn);
-			// the whole match enters the hash table at once
-			for (u32 j = lane; j < len; j += OTZ_ENC_NT) {
-				u32 q = p + j;
-				if (q + 3u <= n) {
-					u32 hq = otz_enc_hash (L.win[q & OTZ_ENC_WMASK], L.win[(q + 1u) & OTZ_ENC_WMASK], L.win[(q + 2u) & OTZ_ENC_WMASK]);
-					L.head[hq] = (u16)q;
-				}
-			}
-			p += len;
-		} else {
-			tb = otz_enc_litlen_bits (L.win[p & OTZ_ENC_WMASK], &tn);
-			if (can_hash && lane == 0) {
-				L.head[h] = (u16)p;
-			}
-			p += 1u;
-		}
-		otz_enc_put (L, S, tb, tn); // the one place the token loop emits bits
 		otz_wave_sync ();
+		const u32 pos = p + lane;
+		const bool can = pos + 3u <= n;
+		u32 h = 0, c16 = 0;
+		if (can) {
+			h = otz_enc_hash (L.win[pos & OTZ_ENC_WMASK], L.win[(pos + 1u) & OTZ_ENC_WMASK], L.win[(pos + 2u) & OTZ_ENC_WMASK]);
+			c16 = L.head[h];
+		}
+		otz_wave_sync (); // every lane has read the heads of the previous steps
+		if (can) {
+			L.head[h] = (u16)pos;
+		}
+		u32 dist = (pos - c16) & 0xFFFFu, len = 0;
+		if (can && dist >= 1u && dist <= OTZ_ENC_MAXDIST && dist <= pos) {
+			u32 maxlen = n - pos < 258u ? n - pos : 258u;
+			while (len < maxlen && L.win[(pos + len) & OTZ_ENC_WMASK] == L.win[(pos - dist + len) & OTZ_ENC_WMASK]) {
+				len++;
+			}
+			if (len < 3u) {
+				len = 0;
+			}
+		}
+		// greedy chain through this step's positions, starting after what the last match covered
+		u32 adv = len ? len : 1u;
+		u64 sel = 0;
+		u32 cur = skip;
+		u32 lim = n - p < 64u ? n - p : 64u;
+		while (cur < lim) {
+			sel |= 1ull << cur;
+			cur += otz_shfl (adv, cur);
+		}
+		skip = cur > 64u ? cur - 64u : 0u;
+		const bool chosen = (sel >> lane) & 1ull;
+		u32 tb = 0, tn = 0;
+		if (chosen) {
+			if (len) {
+				tb = otz_enc_match_bits (len, dist, &tn);
+			} else {
+				tb = otz_enc_litlen_bits (L.win[pos & OTZ_ENC_WMASK], &tn);
+			}
+		}
+		u32 incl = tn;
+#pragma unroll
+		for (u32 d = 1; d < 64; d <<= 1) {
+			u32 o = otz_shfl_up (incl, d);
+			if (lane >= d) {
+				incl += o;
+			}
+		}
+		u32 total = otz_shfl (incl, 63);
+		if (chosen) {
+			otz_enc_or_bits (L, S.bitpos + incl - tn, tb, tn);
+		}
+		S.bitpos += total;
+		otz_enc_drain (L, S);
 	}
-	{
+	otz_wave_sync ();
+	// end of the fixed block, then the final block: stored, empty (BFINAL = 1, BTYPE = 00,
+	// pad to a byte, LEN = 0, NLEN = 0xFFFF)
+	if (lane == 0) {
 		u32 n7;
-		u32 eob = otz_enc_litlen_bits (256u, &n7); // end of the fixed block
-		otz_enc_put (L, S, eob, n7);
+		u32 eob = otz_enc_litlen_bits (256u, &n7);
+		otz_enc_or_bits (L, S.bitpos, eob, n7);
+		otz_enc_or_bits (L, S.bitpos + n7, 1u, 3);
 	}
-	// final block: stored, empty (BFINAL = 1, BTYPE = 00, pad to a byte, LEN = 0, NLEN = 0xFFFF)
-	otz_enc_put (L, S, 1u, 3);
-	if (S.nacc & 7u) {
-		otz_enc_put (L, S, 0u, 8u - (S.nacc & 7u));
+	S.bitpos += 10u;
+	S.bitpos = (S.bitpos + 7u) & ~7u;
+	if (lane == 0) {
+		otz_enc_or_bits (L, S.bitpos, 0xFFFF0000u, 32);
 	}
-	otz_enc_put (L, S, 0xFFFF0000u, 32);
-	// drain the accumulator (whole bytes by construction)
-	while (S.nacc) {
-		if (lane == 0) {
-			reinterpret_cast<u8 *> (L.out_w)[S.stage_fill] = (u8)S.acc;
+	S.bitpos += 32u;
+	otz_wave_sync ();
+	otz_enc_drain (L, S);
+	otz_wave_sync ();
+	u32 tail = S.bitpos >> 3; // whole bytes by construction
+	if (S.out_pos + tail > S.cap) {
+		S.overflow = true;
+	}
+	if (!S.overflow) {
+		const u8 *ob = reinterpret_cast<const u8 *> (L.out_w);
+		for (u32 i = lane; i < tail; i += OTZ_ENC_NT) {
+			S.dst[S.out_pos + i] = ob[i];
 		}
-		S.acc >>= 8;
-		S.nacc -= 8u;
-		S.stage_fill += 1u;
-		if (S.stage_fill == OTZ_ENC_OUT) {
-			otz_enc_flush_stage (L, S);
-		}
 	}
-	otz_enc_flush_stage (L, S);
-	return S.overflow ? ~0u : S.out_pos;
+	return S.overflow ? ~0u : S.out_pos + tail;
 }
 
 // ---------------------------------------------------------------- method 14
@@ -400,6 +406,7 @@ OTZ_DEV void otz_encode_entry(otz_enc_lds &L, const u8 *src, u8 *dst, const ozg_
 	if (e.method == OZG_METHOD_DEFLATE && e.src_size > 0) {
 		u32 cs = otz_deflate_entry (L, in, e.src_size, out, e.dst_cap);
 		stored = cs >= e.src_size; // did not fit, or not smaller: ref otezip.c:846-850
+		otz_wave_sync ();          // the encoder's last stores land before a STORE copy reuses dst
 		if (!stored && lane == 0) {
 			res->status = OZG_ST_OK;
 			res->comp_size = cs;

@@ -59,7 +59,6 @@
 #define OTZ_X_CUT 2u     // stopped after OTZ_TOK_CAP tokens
 #define OTZ_X_INVALID 3u // no code matches / reserved symbol
 #define OTZ_X_TRUNC 4u   // ran past the end of the input
-#define OTZ_X_DEAD 5u    // left neighbour's path terminated: not on the chain
 #define OTZ_X_POS(x) ((x) & 0xFFFFFFu)
 #define OTZ_X_KIND(x) ((x) >> 24)
 #define OTZ_X_MAKE(kind, pos) (((kind) << 24) | (pos))
@@ -115,7 +114,6 @@ struct otz_inflate_lds {
 	u32 hdr_bits;     // header: bits consumed
 	u32 hlit, hdist;
 	u32 bfinal, btype;
-	u32 stored_len;
 	u32 eob_start_lo, eob_start_hi;
 	u32 rej_bytes_incl;
 	u32 acc_bytes;

@@ -1,7 +1,8 @@
 """Ad-hoc GPU diagnostic (not a test): prints per-entry status words for a few seeded cases."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import cases
 import otezip_amd as oz
 from test_gpu_parity import run_gpu
