@@ -687,52 +687,167 @@ OTZ_DEV void otz_parse_header_a(otz_inflate_lds &L, u32 p, u64 avail) {
 	L.hdr_bits = used;
 }
 
-// Work-item 0: decode hlit+hdist code lengths with the 7-bit LUT
-// (ref deflate-dec.inc.c:164-253).
-OTZ_DEV void otz_parse_header_b(otz_inflate_lds &L, u32 p, u64 avail) {
-	otz_br r;
-	otz_br_init (r, L.stage_w, p);
-	u32 used = 0, n = L.hlit + L.hdist, idx = 0;
-	while (idx < n) {
-		otz_br_refill (r, L.stage_w);
-		u32 e = L.cl_lut[(u32)r.bb & 127u];
-		u32 l = e & 15u;
-		if (l == 0) {
-			otz_set_status (L, OZG_ST_DATA);
-			return;
+// Every work-item calls this with the same st: the barriers keep the write to
+// L.status away from work-items that are still reading it.
+OTZ_DEV void otz_fail_all(otz_inflate_lds &L, int st) {
+	otz_sync ();
+	if (otz_tid () == 0) {
+		otz_set_status (L, st);
+	}
+	otz_sync ();
+}
+
+// All work-items: decode the hlit+hdist code lengths of a dynamic block in parallel
+// (ref deflate-dec.inc.c:164-253: symbols 0-15 are lengths, 16 repeats the previous
+// length 3-6 times, 17/18 write 3-10 / 11-138 zeros; a bad code, a repeat with no
+// previous length, a run past hlit+hdist or running out of input is a data error).
+//   1. every bit position i of the length section decodes the one code-length token
+//      that would start there (7-bit LUT + extra bits);
+//   2. every position chains 8 of those tokens: jump[i] = (position after them, lengths
+//      they produce);
+//   3. work-item 0 follows the jumps from position 0 -- at most 41 dependent steps
+//      instead of one per token -- and notes where each group of 8 tokens starts;
+//   4. one work-item per group expands its tokens into ll[]; "repeat previous" runs
+//      (symbol 16) are written as a marker and filled in afterwards.
+// Scratch (token and jump tables) lives in the ring slots of the not-yet-written
+// output region starting at ring index `scr` (4-byte aligned, OTZ_RMAX bytes free).
+#define OTZ_HP_NPOS 2560u // >= 7 bits x 318 lengths + one token
+#define OTZ_HP_GROUP 8u
+#define OTZ_HP_HEADS 64u
+// scr < OTZ_RING and 4-byte aligned; the tables may wrap around the end of the ring once
+OTZ_DEV u32 &otz_scr32(otz_inflate_lds &L, u32 scr, u32 i) {
+	u32 at = scr + 4u * i;
+	at -= at >= OTZ_RING ? OTZ_RING : 0u;
+	return *reinterpret_cast<u32 *> (&L.ring[at]);
+}
+
+OTZ_DEV void otz_parse_lengths_par(otz_inflate_lds &L, u32 p, u64 avail, u32 scr) {
+	static_assert (OTZ_NT >= 320 && OTZ_NT >= OTZ_HP_HEADS * OTZ_HP_GROUP, "one work-item per code length / per token");
+	static_assert ((2u * OTZ_HP_NPOS + OTZ_HP_HEADS) * 4u <= OTZ_RMAX - 4u, "scratch fits the free ring region");
+	static_assert (OTZ_HP_NPOS % OTZ_NT == 0, "whole chunks");
+	const u32 tid = otz_tid ();
+	const u32 n = L.hlit + L.hdist;
+	// a chain that is still valid has spent at most 7 bits per length
+	const u32 npos = 7u * n + 16u < OTZ_HP_NPOS ? 7u * n + 16u : OTZ_HP_NPOS;
+	for (u32 i = tid; i < npos; i += OTZ_NT) {
+		u32 pos = p + i;
+		u32 w = pos >> 5, sh = pos & 31u;
+		u32 bits = otz_alignbit (L.stage_w[w + 1], L.stage_w[w], sh);
+		u32 e = L.cl_lut[bits & 127u];
+		u32 l = e & 15u, sym = e >> 8;
+		u32 info = 0;
+		if (l) {
+			u32 xb = 0, cnt = 1, val = sym;
+			if (sym >= 16u) {
+				xb = sym == 16u ? 2u : sym == 17u ? 3u : 7u;
+				cnt = ((bits >> l) & ((1u << xb) - 1u)) + (sym == 18u ? 11u : 3u);
+				val = sym == 16u ? 0xFFu : 0u;
+			}
+			u32 nb = l + xb;
+			if ((u64)i + nb <= avail) {
+				info = nb | (cnt << 4) | (val << 12) | (1u << 20);
+			}
 		}
-		u32 sym = e >> 8;
-		otz_br_drop (r, l);
-		used += l;
-		if (sym < 16u) {
-			L.ll[idx++] = (u8)sym;
-		} else {
-			u32 xb = sym == 16u ? 2u : sym == 17u ? 3u : 7u;
-			u32 rep = ((u32)r.bb & ((1u << xb) - 1u)) + (sym == 18u ? 11u : 3u);
-			otz_br_drop (r, xb);
-			used += xb;
-			u8 v = 0;
-			if (sym == 16u) {
-				if (idx == 0) {
-					otz_set_status (L, OZG_ST_DATA);
-					return;
+		otz_scr32 (L, scr, i) = info;
+	}
+	otz_sync ();
+	// jumps are built one chunk of OTZ_NT positions at a time, only as far as the chain
+	// from position 0 actually reaches (typical headers end inside the first chunk)
+	u32 wpos = 0, widx = 0, wg = 0; // work-item 0: the chain walk
+	u32 groups = 0;
+	for (u32 base = 0; base < npos; base += OTZ_NT) {
+		{
+			u32 i = base + tid, j = i, c = 0;
+			for (u32 t = 0; t < OTZ_HP_GROUP && j < npos; t++) {
+				u32 info = otz_scr32 (L, scr, j);
+				if (!(info >> 20)) {
+					break;
 				}
-				v = L.ll[idx - 1];
+				c += (info >> 4) & 0xFFu;
+				j += info & 15u;
 			}
-			if (idx + rep > n) {
-				otz_set_status (L, OZG_ST_DATA);
-				return;
-			}
-			for (u32 k = 0; k < rep; k++) {
-				L.ll[idx++] = v;
-			}
+			otz_scr32 (L, scr, OTZ_HP_NPOS + i) = j | (c << 16);
 		}
-		if ((u64)used > avail) {
-			otz_set_status (L, OZG_ST_DATA);
-			return;
+		otz_sync ();
+		if (tid == 0) {
+			u32 verdict = 0; // 1: chain complete, 2: bad
+			while (widx < n && wpos < base + OTZ_NT) {
+				u32 jv = otz_scr32 (L, scr, OTZ_HP_NPOS + wpos);
+				u32 j = jv & 0xFFFFu;
+				if (j == wpos || wg == OTZ_HP_HEADS) { // no valid token here: bad code or out of input
+					verdict = 2;
+					break;
+				}
+				otz_scr32 (L, scr, 2u * OTZ_HP_NPOS + wg) = wpos | (widx << 16);
+				wg++;
+				wpos = j;
+				widx += jv >> 16;
+			}
+			if (widx >= n) {
+				verdict = 1;
+			} else if (wpos >= npos) {
+				verdict = 2;
+			}
+			// verdicts travel in their own words: L.status is only written between
+			// barriers that no work-item can be ahead of (otz_fail_all)
+			L.flag = wg | (verdict << 16);
+			L.first_rej = 0;
+		}
+		otz_sync ();
+		groups = L.flag;
+		if (groups >> 16) {
+			break;
 		}
 	}
-	L.hdr_bits = used;
+	if ((groups >> 16) != 1u) {
+		otz_fail_all (L, OZG_ST_DATA);
+		return;
+	}
+	groups &= 0xFFFFu;
+	// one work-item per token: skip the tokens before it in its group, then expand it
+	if (tid < groups * OTZ_HP_GROUP) {
+		u32 hv = otz_scr32 (L, scr, 2u * OTZ_HP_NPOS + tid / OTZ_HP_GROUP);
+		u32 pos = hv & 0xFFFFu, idx = hv >> 16;
+		u32 info = otz_scr32 (L, scr, pos);
+		for (u32 t = tid % OTZ_HP_GROUP; t > 0 && (info >> 20) && idx < n; t--) {
+			idx += (info >> 4) & 0xFFu;
+			pos += info & 15u;
+			info = pos < npos ? otz_scr32 (L, scr, pos) : 0u;
+		}
+		if ((info >> 20) && idx < n) {
+			u32 cnt = (info >> 4) & 0xFFu, val = (info >> 12) & 0xFFu;
+			if ((val == 0xFFu && idx == 0) || idx + cnt > n) {
+				otz_lds_or (&L.first_rej, 1u);
+			} else {
+				for (u32 k = 0; k < cnt; k++) {
+					L.ll[idx + k] = (u8)val;
+				}
+				if (idx + cnt == n) {
+					L.hdr_bits = pos + (info & 15u);
+				}
+			}
+		}
+	}
+	otz_sync ();
+	if (L.first_rej != 0) {
+		otz_fail_all (L, OZG_ST_DATA);
+		return;
+	}
+	// "repeat previous" markers take the nearest earlier real length
+	u32 v = tid < n ? L.ll[tid] : 0u;
+	const bool marker = v == 0xFFu;
+	if (marker) {
+		u32 j = tid;
+		do {
+			j--;
+			v = L.ll[j];
+		} while (v == 0xFFu);
+	}
+	otz_sync ();
+	if (marker) {
+		L.ll[tid] = (u8)v;
+	}
+	otz_sync ();
 }
 
 // ------------------------------------------------------------------- passes
@@ -766,8 +881,14 @@ struct otz_path {
 #define OTZ_MODE_B 1      // from the true start; stops on a visited position
 #define OTZ_MODE_PREFIX 2 // from the speculative start up to `stop`
 
+// Pass A also notes, per visited token start, the output bytes its path produced before
+// that token (u16, first OTZ_CUM_CAP tokens).  The notes live in the ring slots of the
+// round's own not-yet-written output region, which is free until placement.
+#define OTZ_CUM_CAP 23u
+#define OTZ_CUM_STRIDE (2u * OTZ_CUM_CAP)
+
 template <int MODE>
-OTZ_DEV otz_path otz_walk(const otz_inflate_lds &L, const otz_dec &D, u32 start, u32 s, u32 e, u32 limit_bits, u32 stop, u32 (&vis)[OTZ_VIS_WORDS]) {
+OTZ_DEV otz_path otz_walk(otz_inflate_lds &L, const otz_dec &D, u32 start, u32 s, u32 e, u32 limit_bits, u32 stop, u32 (&vis)[OTZ_VIS_WORDS], u32 cum_idx = 0) {
 	otz_path P;
 	P.bytes = 0;
 	P.syncq = ~0u;
@@ -794,6 +915,9 @@ OTZ_DEV otz_path otz_walk(const otz_inflate_lds &L, const otz_dec &D, u32 start,
 				ck = k;
 			}
 			cw |= 1u << (rel & 31u);
+			if (ntok < OTZ_CUM_CAP) {
+				*reinterpret_cast<u16 *> (&L.ring[OTZ_RIDX (cum_idx + 2u * ntok)]) = (u16)P.bytes;
+			}
 		}
 		if (MODE == OTZ_MODE_B) {
 			u32 k = rel >> 5;
@@ -1030,16 +1154,6 @@ OTZ_DEV void otz_fill_zero(otz_inflate_lds &L, u32 opos, u32 n) {
 
 // ----------------------------------------------------------------- the entry
 
-// Every work-item calls this with the same st: the barriers keep the write to
-// L.status away from work-items that are still reading it.
-OTZ_DEV void otz_fail_all(otz_inflate_lds &L, int st) {
-	otz_sync ();
-	if (otz_tid () == 0) {
-		otz_set_status (L, st);
-	}
-	otz_sync ();
-}
-
 // Decode one entry. All OTZ_NT work-items of the workgroup call this together.
 // Work-item 0 writes *res.
 OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_crc, ozg_result *res) {
@@ -1078,6 +1192,9 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 	while (otz_get_status (L) == 0 && !ended) {
 		// ---- block header
 		u32 byte0 = (u32) (abs_bit >> 3);
+		// the header decode uses the free output region of the ring as scratch; flushing
+		// must come before the stage load (the flush borrows the stage buffer)
+		otz_make_room (L, J, opos, OTZ_RMAX, flushed, crc_reg);
 		otz_sync ();
 		u32 skew = otz_stage_load (L, J, byte0);
 		otz_sync ();
@@ -1155,10 +1272,9 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 				u32 k = otz_canon_lookup (L.cl_c, tid, 1, 7, &l);
 				L.cl_lut[tid] = l ? (((u32)L.cl_sorted[k] << 8) | l) : 0u;
 			}
+			const u32 lens_at = p0 + L.hdr_bits;
 			otz_sync ();
-			if (tid == 0) {
-				otz_parse_header_b (L, p0 + L.hdr_bits, total_bits - abs_bit);
-			}
+			otz_parse_lengths_par (L, lens_at, total_bits - abs_bit, OTZ_RIDX ((opos + 3u) & ~3u));
 			otz_sync ();
 			OTZ_MARK (L, J, OTZ_P_LENGTHS);
 			if (otz_get_status (L) != 0) {
@@ -1182,7 +1298,9 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 		while (!block_done) {
 			u32 room = J.out_cap - opos;
 			u32 limit = room < OTZ_RMAX ? room : OTZ_RMAX;
-			otz_make_room (L, J, opos, limit, flushed, crc_reg);
+			// a full OTZ_RMAX is freed even near the end of the output: passes A/B use
+			// the round's output region as scratch
+			otz_make_room (L, J, opos, OTZ_RMAX, flushed, crc_reg);
 			byte0 = (u32) (abs_bit >> 3);
 			otz_sync ();
 			skew = otz_stage_load (L, J, byte0);
@@ -1203,7 +1321,8 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 			// pass A
 			const u32 s = p0 + tid * OTZ_S_BITS, e = s + OTZ_S_BITS;
 			u32 vis[OTZ_VIS_WORDS] = {};
-			otz_path A = otz_walk<OTZ_MODE_A> (L, D, s, s, e, limit_bits, 0, vis);
+			const u32 cum_idx = ((opos + 1u) & ~1u) + tid * OTZ_CUM_STRIDE;
+			otz_path A = otz_walk<OTZ_MODE_A> (L, D, s, s, e, limit_bits, 0, vis, cum_idx);
 			L.exits[tid] = A.exit;
 			otz_sync ();
 
@@ -1258,8 +1377,19 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 				} else {
 					u32 pre = 0;
 					if (q != s) {
-						u32 dummy[OTZ_VIS_WORDS] = {};
-						pre = otz_walk<OTZ_MODE_PREFIX> (L, D, s, s, e, limit_bits, q, dummy).bytes;
+						// ordinal of q among pass A's token starts -> bytes before it
+						u32 rq = q - s, ord = 0;
+#pragma unroll
+						for (u32 i = 0; i < OTZ_VIS_WORDS; i++) {
+							u32 m = rq >= 32u * (i + 1u) ? 0xFFFFFFFFu : rq > 32u * i ? (1u << (rq & 31u)) - 1u : 0u;
+							ord += otz_popc (vis[i] & m);
+						}
+						if (ord < OTZ_CUM_CAP) {
+							pre = *reinterpret_cast<const u16 *> (&L.ring[OTZ_RIDX (cum_idx + 2u * ord)]);
+						} else {
+							u32 dummy[OTZ_VIS_WORDS] = {};
+							pre = otz_walk<OTZ_MODE_PREFIX> (L, D, s, s, e, limit_bits, q, dummy).bytes;
+						}
 					}
 					bytes = wbytes + A.bytes - pre;
 				}
