@@ -39,6 +39,9 @@
 #endif
 #define OTZ_RING 57344u          // 56 KiB: 32 KiB LZ77 window + one round of output (OTZ_RMAX); not a power of two
 #define OTZ_RIDX(p) ((p) % OTZ_RING) // absolute output position -> ring index (constant modulo: mul_hi + sub)
+// ring index + small offset -> ring index, for i < 2 * OTZ_RING: the hot loops take one
+// OTZ_RIDX per token/match and step with this (compare + subtract) from there
+#define OTZ_RWRAP(i) ((i) >= OTZ_RING ? (i) - OTZ_RING : (i))
 #ifndef OTZ_S_BITS
 #define OTZ_S_BITS 128u         // speculative subsequence per lane per round (at most 256)
 #endif
@@ -1001,13 +1004,15 @@ OTZ_DEV void otz_place(otz_inflate_lds &L, const otz_dec &D, bool active, u32 st
 	}
 	u32 exit_pos = OTZ_X_POS (exit_word);
 	u32 pos = start, run_start = o;
+	u32 ri = OTZ_RIDX (o); // ring index of o
 	while (pos < exit_pos) {
 		otz_tok t = otz_decode_at (L, D, pos);
 		u32 tpos = pos;
 		pos += t.nbits;
 		if (t.kind == OTZ_K_LIT) {
-			L.ring[OTZ_RIDX (o)] = (u8)t.val;
+			L.ring[ri] = (u8)t.val;
 			o++;
+			ri = OTZ_RWRAP (ri + 1u);
 			continue;
 		}
 		otz_mark_final (L, run_start - round_base, o - round_base);
@@ -1031,40 +1036,56 @@ OTZ_DEV void otz_place(otz_inflate_lds &L, const otz_dec &D, bool active, u32 st
 			return;
 		}
 		u32 d = (t.dist - 1u) | ((t.val - 3u) << 15);
-		L.ring[OTZ_RIDX (o)] = (u8)d;
-		L.ring[OTZ_RIDX (o + 1u)] = (u8) (d >> 8);
-		L.ring[OTZ_RIDX (o + 2u)] = (u8) (d >> 16);
+		L.ring[ri] = (u8)d;
+		L.ring[OTZ_RWRAP (ri + 1u)] = (u8) (d >> 8);
+		L.ring[OTZ_RWRAP (ri + 2u)] = (u8) (d >> 16);
 		u32 rel = o - round_base;
 		otz_lds_or (&L.mstart[rel >> 5], 1u << (rel & 31u));
 		o += t.val;
+		ri = OTZ_RWRAP (ri + t.val);
 		run_start = o;
 	}
 	otz_mark_final (L, run_start - round_base, o - round_base);
 }
 
 // Pass C2 ("resolve"): the LZ77 copies, all lanes at once.  Lane j owns the
-// matches that START in bytes [32j, 32j+32) and [32(j+256), ...) of the round's
-// output; it keeps trying its pending matches round-robin and copies one as soon
+// matches that START in the 8-byte granules j, j + OTZ_NT, ... of the round's output
+// (strided, so that every lane works on the same stretch of the round at the same
+// time and the matches it depends on lie mostly in stretches that are already done);
+// it keeps trying the pending matches of a granule round-robin and copies one as soon
 // as every source byte is final (literal, older round, or an already resolved
 // match).  The earliest unresolved match of the round is always ready, so the
 // loop cannot stall.  One loop per wavefront, closed by a ballot: a convergent
 // operation keeps the compiler from peeling the "not ready yet" path into an
 // inner loop, which would park the lanes being waited for (SIMT deadlock).
+#define OTZ_RES_GRAN_LOG 3u // a lane owns the matches that start in 8-byte granules g = lane, lane + OTZ_NT, ...
+#define OTZ_RES_CHUNK 16u   // bytes copied per step (two 8-byte LDS accesses each way)
 OTZ_DEV void otz_resolve(otz_inflate_lds &L, u32 round_base, u32 round_bytes) {
-	const u32 nwords = (round_bytes + 31u) >> 5;
-	u32 w = otz_tid ();
-	u32 pending = w < nwords ? L.mstart[w] : 0u;
+	constexpr u32 GB = 1u << OTZ_RES_GRAN_LOG, GMASK = (1u << GB) - 1u;
+	constexpr u32 FIN_WORDS = OTZ_RMAX / 32u;
+	const u32 ngran = (round_bytes + GB - 1u) >> OTZ_RES_GRAN_LOG;
+	const u32 rb = OTZ_RIDX (round_base); // ring index of the round's first byte
+	u32 g = otz_tid ();
+	u32 pending = g < ngran ? (L.mstart[g >> (5u - OTZ_RES_GRAN_LOG)] >> (GB * (g & (32u / GB - 1u)))) & GMASK : 0u;
 	u32 cand = pending;
-	u32 o = 0, pend = 0, pdist = 0, spins = 0;
+	// the candidate being polled: cb = its bit in the granule (32: none), cd = its parked descriptor
+	u32 cb = 32u, cd = 0;
+	// the match being copied: o = round-relative destination, ri/si = ring indices of
+	// destination and source, pend = bytes left
+	u32 o = 0, ri = 0, si = 0, pend = 0, pdist = 1, spins = 0;
 	bool done = false;
 	for (;;) {
 		bool progressed = false;
+		// ---- 1. who needs a candidate: next granule, or next pending match of this one
+		bool poll = false;
+		u32 b = 0;
 		if (!done && pend == 0) {
 			if (pending == 0) {
-				w += OTZ_NT;
-				if (w < nwords) {
-					pending = L.mstart[w];
+				g += OTZ_NT;
+				if (g < ngran) {
+					pending = (L.mstart[g >> (5u - OTZ_RES_GRAN_LOG)] >> (GB * (g & (32u / GB - 1u)))) & GMASK;
 					cand = pending;
+					cb = 32u;
 					progressed = true;
 				} else {
 					done = true;
@@ -1073,61 +1094,125 @@ OTZ_DEV void otz_resolve(otz_inflate_lds &L, u32 round_base, u32 round_bytes) {
 				if (cand == 0) {
 					cand = pending;
 				}
-				u32 b = otz_ctz (cand);
+				b = otz_ctz (cand);
 				cand &= cand - 1u;
-				u32 at = round_base + 32u * w + b;
-				u32 d = (u32)L.ring[OTZ_RIDX (at)] | ((u32)L.ring[OTZ_RIDX (at + 1u)] << 8) |
-					((u32)L.ring[OTZ_RIDX (at + 2u)] << 16);
-				u32 dist = (d & 0x7FFFu) + 1u, len = (d >> 15) + 3u;
-				u32 s0 = at - dist;
-				u32 e0 = s0 + (len < dist ? len : dist);
-				bool ready = e0 <= round_base;
-				if (!ready) {
-					u32 a = s0 > round_base ? s0 - round_base : 0u;
-					ready = otz_all_final (L, a, e0 - round_base);
+				poll = true;
+			}
+		}
+		const u32 at = GB * g + b; // round-relative start of the candidate
+		const u32 ai = OTZ_RWRAP (rb + at);
+		if (poll && b != cb) { // a retry of the same candidate keeps its descriptor
+			if (ai + 3u <= OTZ_RING) {
+				cd = otz_ld32u (&L.ring[ai]) & 0xFFFFFFu;
+			} else {
+				cd = (u32)L.ring[ai] | ((u32)L.ring[OTZ_RWRAP (ai + 1u)] << 8) | ((u32)L.ring[OTZ_RWRAP (ai + 2u)] << 16);
+			}
+			cb = b;
+		}
+		const u32 dist = (cd & 0x7FFFu) + 1u, len = (cd >> 15) + 3u;
+		// source bytes [at - dist, at - dist + min(len, dist)) must be final; everything
+		// before the round already is
+		const u32 span = len < dist ? len : dist;
+		const u32 fa = at > dist ? at - dist : 0u, fb = at + span - dist; // round-relative [fa, fb) when fb > 0
+		const u32 csi = ai >= dist ? ai - dist : ai + OTZ_RING - dist;
+		// ---- 2. one LDS round trip: the final bits of the candidate's source AND the
+		// next OTZ_RES_CHUNK source bytes (of the candidate, or of the match in flight)
+		const u32 rs = pend != 0 ? si : csi;
+		const u32 w0 = fa >> 5;
+		u32 f0 = otz_lds_load_inorder (&L.fin[w0 < FIN_WORDS ? w0 : 0u]);
+		u32 f1 = otz_lds_load_inorder (&L.fin[w0 + 1u < FIN_WORDS ? w0 + 1u : 0u]);
+		otz_order_loads ();
+		// reads past the bytes used (and past the ring's end) land in the LDS block and are ignored
+		u64 lo = otz_ld64u (&L.ring[rs]), hi = otz_ld64u (&L.ring[rs + 8u]);
+		if (poll) {
+			bool ready;
+			if (dist >= at + span) {
+				ready = true; // source entirely before the round
+			} else if (fb - fa <= 32u) {
+				u64 need = ((((u64)1 << (fb - fa)) - 1u) << (fa & 31u));
+				u64 have = (u64)f0 | ((u64)f1 << 32);
+				ready = (have & need) == need;
+			} else {
+				ready = otz_all_final (L, fa, fb);
+				if (ready) { // the bytes read above may predate the final ones
+					lo = otz_ld64u (&L.ring[csi]);
+					hi = otz_ld64u (&L.ring[csi + 8u]);
 				}
-				if (ready) {
-					o = at;
-					pend = len;
-					pdist = dist;
-					pending &= ~(1u << b);
-				} else if (otz_get_status (L) != 0) {
+			}
+			if (ready) {
+				o = at;
+				ri = ai;
+				si = csi;
+				pend = len;
+				pdist = dist;
+				pending &= ~(1u << b);
+				cb = 32u;
+			} else if ((++spins & 63u) == 0) {
+				if (otz_get_status (L) != 0) {
 					done = true;
-				} else if (++spins > OTZ_SPIN_LIMIT) {
+				} else if (spins > OTZ_SPIN_LIMIT) {
 					L.dbg[0] = 3; // waited too long for source bytes
 					L.dbg[1] = otz_tid ();
-					L.dbg[2] = at;
+					L.dbg[2] = round_base + at;
 					L.dbg[3] = dist | (len << 16);
 					otz_set_status (L, OZG_ST_INTERNAL);
 					done = true;
 				}
 			}
 		}
+		// ---- 3. copy one step
 		if (!done && pend != 0) {
 			progressed = true;
-			u32 n = pend < 8u ? pend : 8u;
-			if (pdist >= n) {
-				u8 tmp[8];
-#pragma unroll
-				for (u32 k = 0; k < 8; k++) {
-					if (k < n) {
-						tmp[k] = L.ring[OTZ_RIDX (o - pdist + k)];
-					}
-				}
-#pragma unroll
-				for (u32 k = 0; k < 8; k++) {
-					if (k < n) {
-						L.ring[OTZ_RIDX (o + k)] = tmp[k];
-					}
-				}
+			// Up to OTZ_RES_CHUNK bytes that neither overlap their own source nor cross
+			// the end of the ring, so every byte is ring[si + k] -> ring[ri + k] with
+			// constant k.  An overlapping match (distance < chunk) copies one period,
+			// then two, four, ... from the same source.
+			u32 n = pend < OTZ_RES_CHUNK ? pend : OTZ_RES_CHUNK;
+			n = n < pdist ? n : pdist;
+			n = n < OTZ_RING - ri ? n : OTZ_RING - ri;
+			n = n < OTZ_RING - si ? n : OTZ_RING - si;
+			u8 *dst = &L.ring[ri];
+			if (n == OTZ_RES_CHUNK) {
+				otz_st64u (dst, lo);
+				otz_st64u (dst + 8, hi);
 			} else {
-				for (u32 k = 0; k < n; k++) {
-					L.ring[OTZ_RIDX (o + k)] = L.ring[OTZ_RIDX (o + k - pdist)];
+				u64 v = lo;
+				if (n & 8u) {
+					otz_st64u (dst, lo);
+					v = hi;
+					dst += 8;
+				}
+				if (n & 4u) {
+					otz_st32u (dst, (u32)v);
+					v >>= 32;
+					dst += 4;
+				}
+				if (n & 2u) {
+					otz_st16u (dst, (u16)v);
+					v >>= 16;
+					dst += 2;
+				}
+				if (n & 1u) {
+					*dst = (u8)v;
 				}
 			}
-			otz_mark_final (L, o - round_base, o + n - round_base);
+			{
+				// bytes [o, o + n) are final: at most two words of the bitmap
+				otz_fence_release ();
+				u64 mask = (((u64)1 << n) - 1u) << (o & 31u);
+				otz_lds_or (&L.fin[o >> 5], (u32)mask);
+				if ((u32) (mask >> 32)) {
+					otz_lds_or (&L.fin[(o >> 5) + 1u], (u32) (mask >> 32));
+				}
+			}
 			o += n;
+			ri = OTZ_RWRAP (ri + n);
 			pend -= n;
+			if (n == pdist && pdist < OTZ_RES_CHUNK) {
+				pdist += n; // a whole period written: same source, twice the reach
+			} else {
+				si = OTZ_RWRAP (si + n); // destination - source stays a multiple of the distance
+			}
 		}
 		u64 alive = otz_ballot (!done);
 		u64 moved = otz_ballot (progressed);

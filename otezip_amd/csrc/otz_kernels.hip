@@ -27,7 +27,10 @@ static_assert (sizeof (otz_inflate_lds) <= 80 * 1024, "two inflate workgroups pe
 
 static_assert (OTZ_NT * OTZ_S_BITS / 8 + 512 <= OTZ_STAGE_BYTES, "stage must cover one round of input");
 
-extern "C" __global__ void __launch_bounds__ (OTZ_NT)
+// Two workgroups per CU (16 waves, 4 per SIMD) need <= 128 VGPRs: pin that occupancy so a
+// register-hungry change fails the resource check in tests/test_abi.py instead of
+// silently halving the number of entries in flight.
+extern "C" __global__ void __launch_bounds__ (OTZ_NT) __attribute__ ((amdgpu_waves_per_eu (4, 4)))
 otz_inflate_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *results, u32 n, ozg_limits lim, u64 *prof) {
 	extern __shared__ __attribute__ ((aligned (16))) u8 otz_smem[];
 	u32 i = blockIdx.x;

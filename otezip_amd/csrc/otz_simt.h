@@ -58,6 +58,12 @@ OTZ_DEV void otz_lds_min(u32 *p, u32 v) { __hip_atomic_fetch_min (p, v, __ATOMIC
 OTZ_DEV void otz_lds_max(u32 *p, u32 v) { __hip_atomic_fetch_max (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 OTZ_DEV u32 otz_lds_add(u32 *p, u32 v) { return __hip_atomic_fetch_add (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 OTZ_DEV u32 otz_lds_load(const u32 *p) { return __hip_atomic_load (p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// Loads that stay in program order among themselves (volatile): the LDS pipeline of a CU
+// executes one wavefront's DS instructions in issue order, so a flag word read this way
+// followed by data bytes read this way observes the data at least as new as the flag --
+// acquire ordering without draining the queue between the two (one round trip, not two).
+OTZ_DEV u32 otz_lds_load_inorder(const u32 *p) { return *reinterpret_cast<const volatile u32 *> (p); }
+OTZ_DEV u32 otz_lds_load8_inorder(const u8 *p) { return *reinterpret_cast<const volatile u8 *> (p); }
 OTZ_DEV void otz_lds_store(u32 *p, u32 v) { __hip_atomic_store (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // LDS is one in-order pipeline per CU; these only stop the compiler (and the
@@ -74,6 +80,26 @@ OTZ_DEV u32 otz_ctz(u32 v) { return (u32)__builtin_ctz (v); }
 OTZ_DEV u32 otz_bfe(u32 v, u32 off, u32 width) { return __builtin_amdgcn_ubfe (v, off, width); }
 // low 32 bits of (hi:lo) >> (sh & 31): v_alignbit_b32
 OTZ_DEV u32 otz_alignbit(u32 hi, u32 lo, u32 sh) { return __builtin_amdgcn_alignbit (hi, lo, sh); }
+
+// Unaligned 2/4/8-byte LDS accesses: gfx950 executes DS instructions at any byte address
+// (the compiler lowers these to single ds_read_b64 / ds_write_b32 / ... instructions), so a
+// byte-granular copy moves 8 bytes per LDS instruction instead of one.
+OTZ_DEV u64 otz_ld64u(const void *p) {
+	u64 v;
+	__builtin_memcpy (&v, p, 8);
+	return v;
+}
+OTZ_DEV u32 otz_ld32u(const void *p) {
+	u32 v;
+	__builtin_memcpy (&v, p, 4);
+	return v;
+}
+OTZ_DEV void otz_st64u(void *p, u64 v) { __builtin_memcpy (p, &v, 8); }
+OTZ_DEV void otz_st32u(void *p, u32 v) { __builtin_memcpy (p, &v, 4); }
+OTZ_DEV void otz_st16u(void *p, u16 v) { __builtin_memcpy (p, &v, 2); }
+// Keeps the compiler from moving memory accesses across this point; emits nothing.  With
+// the in-order LDS pipeline that is all "flag, then data" needs (see otz_lds_load_inorder).
+OTZ_DEV void otz_order_loads() { asm volatile ("" ::: "memory"); }
 
 // 16-byte global accesses.  gfx950 runs with unaligned global access enabled,
 // so an under-aligned source still lowers to one global_load_dwordx4.

@@ -115,6 +115,18 @@ def deflate_large(seed=5):
     return out
 
 
+def deflate_ring_wrap(seed=7, ring=57344):
+    """Overlapping matches (distance < copy chunk) whose first period straddles the end of
+    the kernel's output ring (OTZ_RING bytes): the copy has to split at the wrap without
+    losing the period."""
+    r = _rng(seed)
+    out = []
+    for k, period in ((1, 7), (2, 3), (5, 9), (1, 2), (3, 15), (0, 1), (8, 13)):
+        d = word_text(r, ring - k) + bytes(r.sample(range(1, 255), period)) * 23 + word_text(r, 500)
+        out.append((8, raw_deflate(d), len(d), crc(d), 0))
+    return out
+
+
 def containers(seed=6):
     """STORE and the private framings of methods 93/100/97/14, good and bad."""
     r = _rng(seed)

@@ -91,6 +91,9 @@ OTZ_DEV void otz_lds_max(u32 *p, u32 v) {
 }
 OTZ_DEV u32 otz_lds_add(u32 *p, u32 v) { return __atomic_fetch_add (p, v, __ATOMIC_RELAXED); }
 OTZ_DEV u32 otz_lds_load(const u32 *p) { return __atomic_load_n (p, __ATOMIC_RELAXED); }
+// in-order loads: on the host, acquire loads (x86: plain loads the compiler may not reorder)
+OTZ_DEV u32 otz_lds_load_inorder(const u32 *p) { return __atomic_load_n (p, __ATOMIC_ACQUIRE); }
+OTZ_DEV u32 otz_lds_load8_inorder(const u8 *p) { return __atomic_load_n (p, __ATOMIC_ACQUIRE); }
 OTZ_DEV void otz_lds_store(u32 *p, u32 v) { __atomic_store_n (p, v, __ATOMIC_RELAXED); }
 
 OTZ_DEV void otz_fence_release() { __atomic_thread_fence (__ATOMIC_RELEASE); }
@@ -108,6 +111,21 @@ OTZ_DEV u32 otz_brev(u32 v) {
 OTZ_DEV u32 otz_ctz(u32 v) { return (u32)__builtin_ctz (v); }
 OTZ_DEV u32 otz_bfe(u32 v, u32 off, u32 width) { return (v >> (off & 31u)) & ((1u << (width & 31u)) - 1u); }
 OTZ_DEV u32 otz_alignbit(u32 hi, u32 lo, u32 sh) { return (u32) ((((u64)hi << 32) | lo) >> (sh & 31u)); }
+
+OTZ_DEV u64 otz_ld64u(const void *p) {
+	u64 v;
+	memcpy (&v, p, 8);
+	return v;
+}
+OTZ_DEV u32 otz_ld32u(const void *p) {
+	u32 v;
+	memcpy (&v, p, 4);
+	return v;
+}
+OTZ_DEV void otz_st64u(void *p, u64 v) { memcpy (p, &v, 8); }
+OTZ_DEV void otz_st32u(void *p, u32 v) { memcpy (p, &v, 4); }
+OTZ_DEV void otz_st16u(void *p, u16 v) { memcpy (p, &v, 2); }
+OTZ_DEV void otz_order_loads() { __atomic_thread_fence (__ATOMIC_ACQUIRE); }
 
 OTZ_DEV otz_u4 otz_ld16(const void *p) {
 	otz_u4 v;

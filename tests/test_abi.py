@@ -44,11 +44,32 @@ def test_struct_layouts_match_header(native):
 
 
 def test_code_object_targets_gfx950(native):
-    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", native.lib_path()],
-                         capture_output=True, text=True).stdout
+    # llvm-objdump --offloading drops the extracted code objects next to its input: point
+    # it at a throw-away copy
+    import shutil
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        copy = shutil.copy(native.lib_path(), tmp)
+        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", copy],
+                             capture_output=True, text=True, cwd=tmp).stdout
     if not out.strip():
         pytest.skip("llvm-objdump --offloading unavailable")
     assert "gfx950" in out
+
+
+def test_inflate_kernel_keeps_two_workgroups_per_cu(native):
+    """Occupancy is part of the design: two 512-work-item workgroups per CU
+    need <= 128 VGPRs per work-item and no scratch memory.  The build writes the compiler's
+    resource report next to the object file."""
+    rep = os.path.join(ROOT, "build", "otz_kernels.resources.txt")
+    if not os.path.exists(rep):
+        pytest.skip("no resource report (library was not built in this tree)")
+    txt = open(rep).read()
+    m = re.search(r"Function Name: otz_inflate_kernel.*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?"
+                  r"Occupancy \[waves/SIMD\]: (\d+)", txt, flags=re.S)
+    assert m, "otz_inflate_kernel missing from the resource report"
+    vgprs, scratch, occ = map(int, m.groups())
+    assert vgprs <= 128 and scratch == 0 and occ >= 4, (vgprs, scratch, occ)
 
 
 def test_fails_loudly_without_a_gpu(native):

@@ -41,6 +41,10 @@ def test_deflate_beyond_the_lds_ring():
     _run([items[0], items[2]])  # 64 KiB and 100 000 B of text: several rounds, two flushes
 
 
+def test_deflate_overlapping_matches_across_the_ring_end():
+    _run(cases.deflate_ring_wrap())
+
+
 def test_containers():
     items = [c for c in cases.containers() if c[2] <= 70001]
     _run(items)
