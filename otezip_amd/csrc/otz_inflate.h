@@ -45,7 +45,6 @@
 #ifndef OTZ_S_BITS
 #define OTZ_S_BITS 128u         // speculative subsequence per lane per round (at most 256)
 #endif
-#define OTZ_TOK_CAP 64u         // tokens per pass-A path (bounds lane 0's output: 64 * 258 < OTZ_RMAX)
 #define OTZ_RMAX 24576u         // output bytes per round (size of the bitmaps); OTZ_RING - OTZ_RMAX = the 32 KiB window
 #define OTZ_STAGE_BYTES 8704u   // OTZ_NT * OTZ_S_BITS / 8 = 8192 B + skew + lookahead; also holds the CRC tables
 #define OTZ_STAGE_WORDS (OTZ_STAGE_BYTES / 4)
@@ -59,7 +58,6 @@
 // exit word of a lane's path: [23:0] stage-relative bit position, [26:24] kind
 #define OTZ_X_NORMAL 0u  // first token start at or beyond the lane's range
 #define OTZ_X_EOB 1u     // position just after an end-of-block code
-#define OTZ_X_CUT 2u     // stopped after OTZ_TOK_CAP tokens
 #define OTZ_X_INVALID 3u // no code matches / reserved symbol
 #define OTZ_X_TRUNC 4u   // ran past the end of the input
 #define OTZ_X_POS(x) ((x) & 0xFFFFFFu)
@@ -279,15 +277,12 @@ OTZ_DEV u32 otz_lut2(const u32 *lut, u32 bits) {
 	return e;
 }
 
-// Decode the token (literal / end-of-block / length+distance pair) that starts at
-// stage-relative bit `pos`.  One LDS round trip fetches 64 stream bits, which
-// always cover a whole token (at most 15+5+15+13 = 48 bits); the table lookups
-// follow.  No state is carried from token to token except `pos`.
-OTZ_DEV otz_tok otz_decode_at(const otz_inflate_lds &L, const otz_dec &D, u32 pos) {
+// Decode the token (literal / end-of-block / length+distance pair) whose bits start
+// at bit 0 of (hi:lo): 64 stream bits always cover a whole token (at most
+// 15+5+15+13 = 48 bits).  (Fetching them with one unaligned 8-byte LDS read instead
+// of aligned words measured slower.)
+OTZ_DEV otz_tok otz_decode_bits(const otz_inflate_lds &L, u32 lo, u32 hi) {
 	otz_tok t;
-	u32 w = pos >> 5, sh = pos & 31u;
-	u32 d0 = L.stage_w[w], d1 = L.stage_w[w + 1], d2 = L.stage_w[w + 2];
-	u32 lo = otz_alignbit (d1, d0, sh), hi = otz_alignbit (d2, d1, sh);
 	u32 e = otz_lut2<OTZ_LIT_ROOT> (L.lit_lut, lo);
 	u32 len = e & 15u;
 	t.kind = len ? (e >> 4) & 3u : OTZ_K_BAD;
@@ -305,10 +300,43 @@ OTZ_DEV otz_tok otz_decode_at(const otz_inflate_lds &L, const otz_dec &D, u32 po
 	u32 dl = d & 15u, dxb = (d >> 8) & 15u; // dl + dxb <= 28
 	if (dl == 0 || ((d >> 4) & 3u) != OTZ_K_LEN) {
 		t.kind = OTZ_K_BAD;
+		t.nbits = 0;
 		return t;
 	}
 	t.dist = (d >> 16) + otz_bfe (db, dl, dxb);
 	t.nbits = used + dl + dxb;
+	return t;
+}
+
+// A token walk keeps three stage words (96 stream bits from the word holding the
+// current position) in registers.  Each step asks for the next two words BEFORE it
+// decodes: they arrive while the table lookups are in flight, and the window then
+// slides by 0-2 words to the token's end -- so the stream bits of the next token are
+// already there and a step waits for the table lookups only (one LDS round trip for
+// a literal, two for a match, instead of two and three).
+struct otz_win {
+	u32 w0, w1, w2;
+	u32 a; // stage word index of w0; the current position lies in that word
+};
+OTZ_DEV void otz_win_init(otz_win &W, const otz_inflate_lds &L, u32 pos) {
+	W.a = pos >> 5;
+	W.w0 = L.stage_w[W.a];
+	W.w1 = L.stage_w[W.a + 1u];
+	W.w2 = L.stage_w[W.a + 2u];
+}
+OTZ_DEV otz_tok otz_decode_adv(const otz_inflate_lds &L, otz_win &W, u32 pos) {
+	u32 p0 = L.stage_w[W.a + 3u], p1 = L.stage_w[W.a + 4u];
+	u32 sh = pos & 31u;
+	otz_tok t = otz_decode_bits (L, otz_alignbit (W.w1, W.w0, sh), otz_alignbit (W.w2, W.w1, sh));
+	u32 na = (pos + t.nbits) >> 5; // a token is at most 48 bits: 0-2 words further
+	u32 d = na - W.a;
+	u32 n0 = d == 0 ? W.w0 : d == 1u ? W.w1 : W.w2;
+	u32 n1 = d == 0 ? W.w1 : d == 1u ? W.w2 : p0;
+	u32 n2 = d == 0 ? W.w2 : d == 1u ? p0 : p1;
+	W.w0 = n0;
+	W.w1 = n1;
+	W.w2 = n2;
+	W.a = na;
 	return t;
 }
 
@@ -855,23 +883,25 @@ OTZ_DEV void otz_parse_lengths_par(otz_inflate_lds &L, u32 p, u64 avail, u32 scr
 
 // ------------------------------------------------------------------- passes
 
-// The visited-token-start bitmap of a lane's pass-A path lives in registers: every access
-// goes through compile-time indices (a runtime-indexed array would be demoted to scratch
-// memory, i.e. global-memory round trips inside the hottest loop).
-#define OTZ_VIS_WORDS (OTZ_S_BITS / 32u)
-OTZ_DEV void otz_vis_merge(u32 (&vis)[OTZ_VIS_WORDS], u32 k, u32 bits) {
-#pragma unroll
-	for (u32 i = 0; i < OTZ_VIS_WORDS; i++) {
-		vis[i] |= k == i ? bits : 0u;
-	}
+// The visited-token-start bitmap of a lane's pass-A path lives in registers, as two
+// 64-bit halves (a runtime-indexed array would be demoted to scratch memory, i.e.
+// global-memory round trips inside the hottest loop).
+static_assert (OTZ_S_BITS == 128u, "otz_vis covers a 128-bit range");
+struct otz_vis {
+	u64 lo, hi;
+};
+OTZ_DEV void otz_vis_set(otz_vis &v, u32 rel) {
+	u64 bit = (u64)1 << (rel & 63u);
+	v.lo |= rel < 64u ? bit : 0u;
+	v.hi |= rel < 64u ? 0u : bit;
 }
-OTZ_DEV u32 otz_vis_pick(const u32 (&vis)[OTZ_VIS_WORDS], u32 k) {
-	u32 w = 0;
-#pragma unroll
-	for (u32 i = 0; i < OTZ_VIS_WORDS; i++) {
-		w |= k == i ? vis[i] : 0u;
-	}
-	return w;
+OTZ_DEV bool otz_vis_test(const otz_vis &v, u32 rel) {
+	return (((rel < 64u ? v.lo : v.hi) >> (rel & 63u)) & 1u) != 0;
+}
+// visited positions below rel
+OTZ_DEV u32 otz_vis_rank(const otz_vis &v, u32 rel) {
+	u64 below = ((u64)1 << (rel & 63u)) - 1u;
+	return rel < 64u ? otz_popc64 (v.lo & below) : otz_popc64 (v.lo) + otz_popc64 (v.hi & below);
 }
 
 struct otz_path {
@@ -886,70 +916,58 @@ struct otz_path {
 
 // Pass A also notes, per visited token start, the output bytes its path produced before
 // that token (u16, first OTZ_CUM_CAP tokens).  The notes live in the ring slots of the
-// round's own not-yet-written output region, which is free until placement.
+// round's own not-yet-written output region, which is free until placement.  `notes`
+// points at the lane's record; note_cap is 0 for the one lane whose record would
+// straddle the end of the ring (it falls back to re-walking its prefix).
 #define OTZ_CUM_CAP 23u
 #define OTZ_CUM_STRIDE (2u * OTZ_CUM_CAP)
 
+// A range of OTZ_S_BITS bits holds at most OTZ_S_BITS tokens, of which at most half are
+// matches (a match is at least two bits): a lane's path yields < 64 * 258 + 64 bytes,
+// which always fits a round (OTZ_RMAX) and a u16 note.
 template <int MODE>
-OTZ_DEV otz_path otz_walk(otz_inflate_lds &L, const otz_dec &D, u32 start, u32 s, u32 e, u32 limit_bits, u32 stop, u32 (&vis)[OTZ_VIS_WORDS], u32 cum_idx = 0) {
+OTZ_DEV otz_path otz_walk(otz_inflate_lds &L, const otz_dec &D, u32 start, u32 s, u32 e, u32 limit_bits, u32 stop, otz_vis &vis, u16 *notes = nullptr, u32 note_cap = 0) {
 	otz_path P;
-	P.bytes = 0;
 	P.syncq = ~0u;
-	P.exit = 0;
-	u32 pos = start, ntok = 0;
+	u32 pos = start, ntok = 0, bytes = 0;
+	u32 xk = OTZ_X_NORMAL;
 	const u32 end = MODE == OTZ_MODE_PREFIX ? stop : e;
-	const bool near_end = e + 64u > limit_bits; // only the lanes at the end of the input check for truncation
-	u32 cw = 0, ck = 0;                         // MODE_A: visited bits of the 32-bit word being filled
-	for (;;) {
-		if (pos >= end) {
-			P.exit = OTZ_X_MAKE (OTZ_X_NORMAL, pos);
-			break;
-		}
-		u32 rel = pos - s; // pos >= s always (a left neighbour exits at or after s)
+	otz_win W;
+	otz_win_init (W, L, pos);
+	while (pos < end) {
+		const u32 rel = pos - s; // pos >= s always (a left neighbour exits at or after s)
 		if (MODE == OTZ_MODE_A) {
-			if (ntok >= OTZ_TOK_CAP) {
-				P.exit = OTZ_X_MAKE (OTZ_X_CUT, pos);
-				break;
-			}
-			u32 k = rel >> 5;
-			if (k != ck) {
-				otz_vis_merge (vis, ck, cw);
-				cw = 0;
-				ck = k;
-			}
-			cw |= 1u << (rel & 31u);
-			if (ntok < OTZ_CUM_CAP) {
-				*reinterpret_cast<u16 *> (&L.ring[OTZ_RIDX (cum_idx + 2u * ntok)]) = (u16)P.bytes;
+			otz_vis_set (vis, rel);
+			if (ntok < note_cap) {
+				notes[ntok] = (u16)bytes;
 			}
 		}
 		if (MODE == OTZ_MODE_B) {
-			u32 k = rel >> 5;
-			u32 w = otz_vis_pick (vis, k);
-			if ((w >> (rel & 31u)) & 1u) {
+			if (otz_vis_test (vis, rel)) {
 				P.syncq = pos;
 				break;
 			}
 		}
-		otz_tok t = otz_decode_at (L, D, pos);
-		if (t.kind == OTZ_K_BAD) {
-			P.exit = OTZ_X_MAKE (pos >= limit_bits ? OTZ_X_TRUNC : OTZ_X_INVALID, pos);
+		const otz_tok t = otz_decode_adv (L, W, pos);
+		const u32 npos = pos + t.nbits;
+		if (t.kind >= OTZ_K_EOB || npos > limit_bits) {
+			// the rare ways out; pos stays at the token's start except after an end-of-block code
+			if (t.kind == OTZ_K_BAD) {
+				xk = pos >= limit_bits ? OTZ_X_TRUNC : OTZ_X_INVALID;
+			} else if (npos > limit_bits) {
+				xk = OTZ_X_TRUNC;
+			} else {
+				xk = OTZ_X_EOB;
+				pos = npos;
+			}
 			break;
 		}
-		if (near_end && pos + t.nbits > limit_bits) {
-			P.exit = OTZ_X_MAKE (OTZ_X_TRUNC, pos);
-			break;
-		}
-		pos += t.nbits;
+		pos = npos;
 		ntok++;
-		if (t.kind == OTZ_K_EOB) {
-			P.exit = OTZ_X_MAKE (OTZ_X_EOB, pos);
-			break;
-		}
-		P.bytes += t.kind == OTZ_K_LIT ? 1u : t.val;
+		bytes += t.kind == OTZ_K_LIT ? 1u : t.val;
 	}
-	if (MODE == OTZ_MODE_A) {
-		otz_vis_merge (vis, ck, cw);
-	}
+	P.exit = OTZ_X_MAKE (xk, pos);
+	P.bytes = bytes;
 	return P;
 }
 
@@ -1005,8 +1023,10 @@ OTZ_DEV void otz_place(otz_inflate_lds &L, const otz_dec &D, bool active, u32 st
 	u32 exit_pos = OTZ_X_POS (exit_word);
 	u32 pos = start, run_start = o;
 	u32 ri = OTZ_RIDX (o); // ring index of o
+	otz_win W;
+	otz_win_init (W, L, pos);
 	while (pos < exit_pos) {
-		otz_tok t = otz_decode_at (L, D, pos);
+		otz_tok t = otz_decode_adv (L, W, pos);
 		u32 tpos = pos;
 		pos += t.nbits;
 		if (t.kind == OTZ_K_LIT) {
@@ -1405,9 +1425,11 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 			OTZ_COUNT (L, J, OTZ_P_ROUNDS, 1);
 			// pass A
 			const u32 s = p0 + tid * OTZ_S_BITS, e = s + OTZ_S_BITS;
-			u32 vis[OTZ_VIS_WORDS] = {};
-			const u32 cum_idx = ((opos + 1u) & ~1u) + tid * OTZ_CUM_STRIDE;
-			otz_path A = otz_walk<OTZ_MODE_A> (L, D, s, s, e, limit_bits, 0, vis, cum_idx);
+			otz_vis vis = { 0, 0 };
+			const u32 note_at = OTZ_RIDX (((opos + 1u) & ~1u) + tid * OTZ_CUM_STRIDE);
+			u16 *const notes = reinterpret_cast<u16 *> (&L.ring[note_at]);
+			const u32 note_cap = note_at + OTZ_CUM_STRIDE <= OTZ_RING ? OTZ_CUM_CAP : 0u;
+			otz_path A = otz_walk<OTZ_MODE_A> (L, D, s, s, e, limit_bits, 0, vis, notes, note_cap);
 			L.exits[tid] = A.exit;
 			otz_sync ();
 
@@ -1463,16 +1485,11 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 					u32 pre = 0;
 					if (q != s) {
 						// ordinal of q among pass A's token starts -> bytes before it
-						u32 rq = q - s, ord = 0;
-#pragma unroll
-						for (u32 i = 0; i < OTZ_VIS_WORDS; i++) {
-							u32 m = rq >= 32u * (i + 1u) ? 0xFFFFFFFFu : rq > 32u * i ? (1u << (rq & 31u)) - 1u : 0u;
-							ord += otz_popc (vis[i] & m);
-						}
-						if (ord < OTZ_CUM_CAP) {
-							pre = *reinterpret_cast<const u16 *> (&L.ring[OTZ_RIDX (cum_idx + 2u * ord)]);
+						u32 ord = otz_vis_rank (vis, q - s);
+						if (ord < note_cap) {
+							pre = notes[ord];
 						} else {
-							u32 dummy[OTZ_VIS_WORDS] = {};
+							otz_vis dummy = { 0, 0 };
 							pre = otz_walk<OTZ_MODE_PREFIX> (L, D, s, s, e, limit_bits, q, dummy).bytes;
 						}
 					}
