@@ -1020,52 +1020,75 @@ OTZ_DEV void otz_place(otz_inflate_lds &L, const otz_dec &D, bool active, u32 st
 	if (!active) {
 		return;
 	}
-	u32 exit_pos = OTZ_X_POS (exit_word);
-	u32 pos = start, run_start = o;
-	u32 ri = OTZ_RIDX (o); // ring index of o
+	const u32 exit_pos = OTZ_X_POS (exit_word);
+	u32 pos = start;
+	u32 rel = o - round_base; // round-relative output position
+	u32 ri = OTZ_RIDX (o);    // its ring index
+	// bits of the bitmap word being filled: literal bytes (final) and match starts.  They
+	// go to LDS when the output moves on to the next word; nobody reads the bitmaps
+	// before the barrier after this pass, so no ordering is needed.
+	u32 curw = rel >> 5, finm = 0, stm = 0;
+	u32 kind = OTZ_K_LIT, tpos = pos, tbits = 0;
 	otz_win W;
 	otz_win_init (W, L, pos);
 	while (pos < exit_pos) {
-		otz_tok t = otz_decode_adv (L, W, pos);
-		u32 tpos = pos;
+		const otz_tok t = otz_decode_adv (L, W, pos);
+		kind = t.kind;
+		tpos = pos;
+		tbits = t.nbits;
+		if (kind >= OTZ_K_EOB) {
+			break;
+		}
 		pos += t.nbits;
-		if (t.kind == OTZ_K_LIT) {
+		const u32 w = rel >> 5;
+		if (w != curw) {
+			if (finm) {
+				otz_lds_or (&L.fin[curw], finm);
+			}
+			if (stm) {
+				otz_lds_or (&L.mstart[curw], stm);
+			}
+			curw = w;
+			finm = stm = 0;
+		}
+		const u32 bit = 1u << (rel & 31u);
+		if (kind == OTZ_K_LIT) {
 			L.ring[ri] = (u8)t.val;
-			o++;
+			finm |= bit;
+			rel++;
 			ri = OTZ_RWRAP (ri + 1u);
 			continue;
 		}
-		otz_mark_final (L, run_start - round_base, o - round_base);
-		if (t.kind == OTZ_K_EOB) {
-			u64 a = stage_abs_bit + tpos;
-			L.eob_start_lo = (u32)a;
-			L.eob_start_hi = (u32) (a >> 32);
-			return;
-		}
-		if (t.kind != OTZ_K_LEN) {
-			L.dbg[0] = 2; // validated path cannot hold a bad token
-			L.dbg[1] = otz_tid ();
-			L.dbg[2] = tpos;
-			L.dbg[3] = t.kind | (t.nbits << 8);
-			otz_set_status (L, OZG_ST_INTERNAL);
-			return;
-		}
-		if (t.dist > o) {
+		if (t.dist > round_base + rel) {
 			// ref reads window bytes nobody wrote (:524): no parity, fail cleanly
 			otz_set_status (L, OZG_ST_DATA);
-			return;
+			break;
 		}
-		u32 d = (t.dist - 1u) | ((t.val - 3u) << 15);
+		const u32 d = (t.dist - 1u) | ((t.val - 3u) << 15);
 		L.ring[ri] = (u8)d;
 		L.ring[OTZ_RWRAP (ri + 1u)] = (u8) (d >> 8);
 		L.ring[OTZ_RWRAP (ri + 2u)] = (u8) (d >> 16);
-		u32 rel = o - round_base;
-		otz_lds_or (&L.mstart[rel >> 5], 1u << (rel & 31u));
-		o += t.val;
+		stm |= bit;
+		rel += t.val;
 		ri = OTZ_RWRAP (ri + t.val);
-		run_start = o;
 	}
-	otz_mark_final (L, run_start - round_base, o - round_base);
+	if (finm) {
+		otz_lds_or (&L.fin[curw], finm);
+	}
+	if (stm) {
+		otz_lds_or (&L.mstart[curw], stm);
+	}
+	if (kind == OTZ_K_EOB) {
+		u64 a = stage_abs_bit + tpos;
+		L.eob_start_lo = (u32)a;
+		L.eob_start_hi = (u32) (a >> 32);
+	} else if (kind == OTZ_K_BAD) {
+		L.dbg[0] = 2; // validated path cannot hold a bad token
+		L.dbg[1] = otz_tid ();
+		L.dbg[2] = tpos;
+		L.dbg[3] = kind | (tbits << 8);
+		otz_set_status (L, OZG_ST_INTERNAL);
+	}
 }
 
 // Pass C2 ("resolve"): the LZ77 copies, all lanes at once.  Lane j owns the
