@@ -1162,8 +1162,8 @@ OTZ_DEV void otz_resolve(otz_inflate_lds &L, u32 round_base, u32 round_bytes) {
 		// next OTZ_RES_CHUNK source bytes (of the candidate, or of the match in flight)
 		const u32 rs = pend != 0 ? si : csi;
 		const u32 w0 = fa >> 5;
-		u32 f0 = otz_lds_load_inorder (&L.fin[w0 < FIN_WORDS ? w0 : 0u]);
-		u32 f1 = otz_lds_load_inorder (&L.fin[w0 + 1u < FIN_WORDS ? w0 + 1u : 0u]);
+		u32 f0 = otz_lds_load (&L.fin[w0 < FIN_WORDS ? w0 : 0u]);
+		u32 f1 = otz_lds_load (&L.fin[w0 + 1u < FIN_WORDS ? w0 + 1u : 0u]);
 		otz_order_loads ();
 		// reads past the bytes used (and past the ring's end) land in the LDS block and are ignored
 		u64 lo = otz_ld64u (&L.ring[rs]), hi = otz_ld64u (&L.ring[rs + 8u]);

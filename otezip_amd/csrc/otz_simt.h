@@ -58,12 +58,12 @@ OTZ_DEV void otz_lds_min(u32 *p, u32 v) { __hip_atomic_fetch_min (p, v, __ATOMIC
 OTZ_DEV void otz_lds_max(u32 *p, u32 v) { __hip_atomic_fetch_max (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 OTZ_DEV u32 otz_lds_add(u32 *p, u32 v) { return __hip_atomic_fetch_add (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 OTZ_DEV u32 otz_lds_load(const u32 *p) { return __hip_atomic_load (p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-// Loads that stay in program order among themselves (volatile): the LDS pipeline of a CU
-// executes one wavefront's DS instructions in issue order, so a flag word read this way
-// followed by data bytes read this way observes the data at least as new as the flag --
-// acquire ordering without draining the queue between the two (one round trip, not two).
-OTZ_DEV u32 otz_lds_load_inorder(const u32 *p) { return *reinterpret_cast<const volatile u32 *> (p); }
-OTZ_DEV u32 otz_lds_load8_inorder(const u8 *p) { return *reinterpret_cast<const volatile u8 *> (p); }
+// "Flag, then data" without draining the LDS queue in between: the LDS pipeline of a CU
+// executes one wavefront's DS instructions in issue order, so a flag word loaded with
+// otz_lds_load followed -- after otz_order_loads(), which only stops the COMPILER from
+// moving memory accesses -- by data loads observes the data at least as new as the
+// flag.  That is acquire ordering in one LDS round trip instead of two.  (A volatile
+// load is not an option: it is lowered to a system-coherent FLAT load.)
 OTZ_DEV void otz_lds_store(u32 *p, u32 v) { __hip_atomic_store (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // LDS is one in-order pipeline per CU; these only stop the compiler (and the

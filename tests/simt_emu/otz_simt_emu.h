@@ -91,9 +91,6 @@ OTZ_DEV void otz_lds_max(u32 *p, u32 v) {
 }
 OTZ_DEV u32 otz_lds_add(u32 *p, u32 v) { return __atomic_fetch_add (p, v, __ATOMIC_RELAXED); }
 OTZ_DEV u32 otz_lds_load(const u32 *p) { return __atomic_load_n (p, __ATOMIC_RELAXED); }
-// in-order loads: on the host, acquire loads (x86: plain loads the compiler may not reorder)
-OTZ_DEV u32 otz_lds_load_inorder(const u32 *p) { return __atomic_load_n (p, __ATOMIC_ACQUIRE); }
-OTZ_DEV u32 otz_lds_load8_inorder(const u8 *p) { return __atomic_load_n (p, __ATOMIC_ACQUIRE); }
 OTZ_DEV void otz_lds_store(u32 *p, u32 v) { __atomic_store_n (p, v, __ATOMIC_RELAXED); }
 
 OTZ_DEV void otz_fence_release() { __atomic_thread_fence (__ATOMIC_RELEASE); }
