@@ -96,11 +96,8 @@ struct otz_inflate_lds {
 		u32 mstart[OTZ_RMAX / 32]; // pass C: an unresolved match starts at this byte
 		u32 exits[OTZ_NT];         // pass A/B: per-lane exit word
 		struct {                   // header parse + table build only
-			u16 lit_sorted[288];
-			u16 dist_sorted[32];
-			otz_canon lit_c, dist_c, cl_c;
-			u8 cl_sorted[20];
-			u8 cl_len[20];
+			u32 wcnt[6][16]; // table build: symbols of each code length per wavefront
+			otz_canon lit_c, dist_c;
 			u32 cl_lut[128];
 			u32 hist[16 * 2]; // code length histograms (lit, dist)
 		};
@@ -113,8 +110,6 @@ struct otz_inflate_lds {
 	u32 first_rej;
 	u32 next_start;
 	u32 hdr_bits;     // header: bits consumed
-	u32 hlit, hdist;
-	u32 bfinal, btype;
 	u32 eob_start_lo, eob_start_hi;
 	u32 rej_bytes_incl;
 	u32 acc_bytes;
@@ -212,47 +207,6 @@ OTZ_DEV u32 otz_mk_dist_entry(u32 sym, u32 len) {
 		base = 1u + ((2u + (sym & 1u)) << xb);
 	}
 	return (base << 16) | (xb << 8) | (OTZ_K_LEN << 4) | len;
-}
-
-// canonical decode of the code that starts at the low bits of `bits`
-// (stream order, LSB first), trying lengths lo..hi
-OTZ_DEV u32 otz_canon_lookup(const otz_canon &c, u32 bits, u32 lo, u32 hi, u32 *len_out) {
-	u32 rev = otz_brev (bits);
-	for (u32 l = lo; l <= hi; l++) {
-		u32 code = rev >> (32u - l);
-		u32 idx = code - (u32)c.first[l];
-		if (idx < (u32)c.count[l]) {
-			*len_out = l;
-			return (u32)c.off[l] + idx;
-		}
-	}
-	*len_out = 0;
-	return 0;
-}
-
-struct otz_br {
-	u64 bb;
-	u32 bc;
-	u32 nw;
-};
-
-OTZ_DEV void otz_br_init(otz_br &r, const u32 *sw, u32 bitpos) {
-	u32 w = bitpos >> 5, s = bitpos & 31u;
-	r.bb = (u64) (sw[w] >> s);
-	r.bc = 32u - s;
-	r.nw = w + 1u;
-}
-OTZ_DEV void otz_br_refill(otz_br &r, const u32 *sw) {
-	if (r.bc <= 32u) {
-		u32 w = r.nw < OTZ_STAGE_WORDS ? sw[r.nw] : 0u;
-		r.bb |= (u64)w << r.bc;
-		r.bc += 32u;
-		r.nw++;
-	}
-}
-OTZ_DEV void otz_br_drop(otz_br &r, u32 n) {
-	r.bb >>= n;
-	r.bc -= n;
 }
 
 struct otz_tok {
@@ -497,100 +451,129 @@ OTZ_DEV bool otz_canon_build(otz_canon &c, const u32 *hist) {
 	return true;
 }
 
-// Rank symbols of each length in index order (one wavefront, ballot-based).
-OTZ_DEV void otz_sort_syms(const otz_canon &c, const u8 *ll, u32 n, u16 *sorted) {
-	u32 lane = otz_lane ();
-	u64 lt = (1ull << lane) - 1ull;
-	for (u32 l = 1; l <= 15; l++) {
-		if (c.count[l] == 0) {
-			continue;
-		}
-		u32 base = c.off[l];
-		for (u32 s0 = 0; s0 < n; s0 += 64) {
-			u32 sym = s0 + lane;
-			bool mine = sym < n && ll[sym] == l;
-			u64 m = otz_ballot (mine);
-			if (mine) {
-				sorted[base + otz_popc64 (m & lt)] = (u16)sym;
+// Build both two-level decode tables from L.ll[0..hlit+hdist).  All work-items;
+// returns false (uniformly) on an over-subscribed set, or if the sub-tables do not
+// fit (which no code set a compressor emits can cause).
+//
+// One work-item per SYMBOL (wavefronts 0-4: the 288 literal/length symbols, wavefront
+// 5: the 32 distance symbols).  A symbol's canonical code is first[len] + its rank
+// among the symbols of the same length, and the rank comes from wavefront ballots --
+// no sorted symbol list is ever materialised.  The symbol then writes its own root
+// slots (code no longer than the root), or claims a sub-table under its root slot.
+OTZ_DEV bool otz_build_tables(otz_inflate_lds &L, u32 hlit, u32 hdist) {
+	static_assert (OTZ_NT >= 384 && OTZ_NT >= (1u << OTZ_LIT_ROOT), "one work-item per symbol and per literal root slot");
+	constexpr u32 LRSZ = 1u << OTZ_LIT_ROOT, DRSZ = 1u << OTZ_DIST_ROOT;
+	const u32 tid = otz_opaque (otz_tid ()), lane = otz_lane (), wave = otz_wave ();
+	const bool is_dist = tid >= 320u;
+	const u32 sym = is_dist ? tid - 320u : tid;
+	u32 l = 0;
+	if (!is_dist && sym < hlit) {
+		l = L.ll[sym];
+	} else if (is_dist && sym < hdist) {
+		l = L.ll[hlit + sym];
+	}
+	for (u32 i = tid; i < OTZ_LIT_LUT; i += OTZ_NT) {
+		L.lit_lut[i] = 0;
+	}
+	for (u32 i = tid; i < OTZ_DIST_LUT; i += OTZ_NT) {
+		L.dist_lut[i] = 0;
+	}
+	u32 rank = 0; // symbols of the same length before this one in its wavefront
+	if (wave < 6u) {
+		const u64 below = ((u64)1 << lane) - 1u;
+		for (u32 k = 1; k <= 15u; k++) {
+			u64 m = otz_ballot (l == k);
+			if (l == k) {
+				rank = otz_popc64 (m & below);
 			}
-			base += otz_popc64 (m);
-		}
-	}
-}
-
-// Two-level decode table from the canonical bookkeeping + sorted symbols.  All
-// work-items.  Returns false (uniformly) if the sub-tables do not fit, which no
-// code set a compressor emits can cause.
-template <u32 ROOT, u32 CAP, bool LIT>
-OTZ_DEV bool otz_fill_lut(otz_inflate_lds &L, u32 *lut, const otz_canon &c, const u16 *sorted) {
-	const u32 tid = otz_tid ();
-	const u32 RSZ = 1u << ROOT;
-	// root slots of the codes that fit the root; 0 elsewhere
-	for (u32 i = tid; i < CAP; i += OTZ_NT) {
-		u32 e = 0;
-		if (i < RSZ) {
-			u32 l;
-			u32 k = otz_canon_lookup (c, i, 1, ROOT, &l);
-			if (l) {
-				e = LIT ? otz_mk_lit_entry (sorted[k], l) : otz_mk_dist_entry (sorted[k], l);
-			}
-		}
-		lut[i] = e;
-	}
-	otz_sync ();
-	// longer codes: work-item k takes the k-th long symbol (canonical order)
-	const u32 long0 = c.off[ROOT + 1];
-	const u32 nsym = (u32)c.off[15] + c.count[15];
-	const u32 k = long0 + tid;
-	for (u32 kk = k; kk < nsym; kk += OTZ_NT) { // at most 2 trips (288 symbols)
-		u32 ll = ROOT + 1;
-		while (ll < 15 && kk >= (u32)c.off[ll] + c.count[ll]) {
-			ll++;
-		}
-		u32 code = (u32)c.first[ll] + (kk - c.off[ll]);
-		u32 rr = otz_brev (code) >> (32u - ll);
-		otz_lds_max (&lut[rr & (RSZ - 1u)], (ll - ROOT) << 8); // widest code under this root slot
-	}
-	otz_sync ();
-	// sub-table placement: prefix sum of 2^bits over the root slots (RSZ / 256 per work-item)
-	const u32 per = (RSZ + OTZ_NT - 1u) / OTZ_NT;
-	u32 mine = 0;
-	for (u32 j = 0; j < per; j++) {
-		u32 i = tid * per + j;
-		u32 e = i < RSZ ? lut[i] : 0u;
-		if (e && (e & 15u) == 0) {
-			mine += 1u << (e >> 8);
-		}
-	}
-	u32 total;
-	u32 incl = otz_block_scan_incl (mine, L.scan, &total);
-	u32 at = RSZ + incl - mine;
-	if (total <= CAP - RSZ) {
-		for (u32 j = 0; j < per; j++) {
-			u32 i = tid * per + j;
-			u32 e = i < RSZ ? lut[i] : 0u;
-			if (e && (e & 15u) == 0) {
-				u32 sb = e >> 8;
-				lut[i] = (at << 16) | (sb << 8) | (OTZ_K_LEN << 4);
-				at += 1u << sb;
+			if (lane == 0) {
+				L.wcnt[wave][k] = otz_popc64 (m);
 			}
 		}
 	}
 	otz_sync ();
-	if (total > CAP - RSZ) {
+	// Canonical bookkeeping, one lane per code length (wavefront 0: literal/length code,
+	// wavefront 1: distance code): first[l] = sum over j < l of count[j] << (l - j),
+	// off[l] = sum over j < l of count[j].  A set is over-subscribed (ref: "left < 0")
+	// exactly when first[15] + count[15] exceeds 2^15.
+	if (wave < 2u) {
+		u32 cnt = 0;
+		if (lane >= 1u && lane < 16u) {
+			const u32 *wc = &L.wcnt[0][0] + lane; // one address, constant offsets
+			cnt = wave == 1u ? wc[80] : wc[0] + wc[16] + wc[32] + wc[48] + wc[64];
+		}
+		u32 code = 0, off = 0;
+		for (u32 j = 1; j < 15u; j++) {
+			u32 cj = otz_shfl (cnt, j);
+			if (lane > j && lane < 16u) {
+				code += cj << (lane - j);
+				off += cj;
+			}
+		}
+		if (lane < 16u) {
+			otz_canon &c = wave == 1u ? L.dist_c : L.lit_c;
+			c.first[lane] = (u16)code;
+			c.count[lane] = (u16)cnt;
+			c.off[lane] = (u16)off;
+		}
+		if (lane == 15u) {
+			u32 ok = code + cnt <= (1u << 15) ? 1u : 0u;
+			if (wave == 0) {
+				L.flag = ok;
+			} else {
+				L.first_rej = ok;
+			}
+		}
+	}
+	otz_sync ();
+	if (L.flag == 0u || L.first_rej == 0u) {
 		return false;
 	}
-	for (u32 kk = k; kk < nsym; kk += OTZ_NT) {
-		u32 ll = ROOT + 1;
-		while (ll < 15 && kk >= (u32)c.off[ll] + c.count[ll]) {
-			ll++;
+	// the symbol's code, bit-reversed (DEFLATE sends codes most significant bit first)
+	const u32 root = is_dist ? OTZ_DIST_ROOT : OTZ_LIT_ROOT, rsz = is_dist ? DRSZ : LRSZ;
+	u32 *const lut = is_dist ? L.dist_lut : L.lit_lut;
+	u32 rr = 0, e = 0;
+	if (l) {
+		const otz_canon &c = is_dist ? L.dist_c : L.lit_c;
+		u32 before = rank;
+		for (u32 w = 0; w < wave && !is_dist; w++) {
+			before += L.wcnt[w][l];
 		}
-		u32 rr = otz_brev ((u32)c.first[ll] + (kk - c.off[ll])) >> (32u - ll);
-		u32 link = lut[rr & (RSZ - 1u)];
+		rr = otz_brev ((u32)c.first[l] + before) >> (32u - l);
+		e = is_dist ? otz_mk_dist_entry (sym, l) : otz_mk_lit_entry (sym, l);
+		if (l <= root) {
+			for (u32 idx = rr; idx < rsz; idx += 1u << l) {
+				lut[idx] = e;
+			}
+		} else {
+			otz_lds_max (&lut[rr & (rsz - 1u)], (l - root) << 8); // widest code under this root slot
+		}
+	}
+	otz_sync ();
+	// sub-table placement: one prefix sum over the root slots of both tables (literal
+	// sizes in the low half of the scanned word, distance sizes in the high half)
+	u32 el = L.lit_lut[tid < LRSZ ? tid : 0u], ed = L.dist_lut[tid < DRSZ ? tid : 0u];
+	u32 ml = tid < LRSZ && el && (el & 15u) == 0 ? 1u << (el >> 8) : 0u;
+	u32 md = tid < DRSZ && ed && (ed & 15u) == 0 ? 1u << (ed >> 8) : 0u;
+	u32 total;
+	u32 incl = otz_block_scan_incl (ml | (md << 16), L.scan, &total);
+	const bool fits = (total & 0xFFFFu) <= OTZ_LIT_LUT - LRSZ && (total >> 16) <= OTZ_DIST_LUT - DRSZ;
+	if (fits) {
+		if (ml) {
+			L.lit_lut[tid] = ((LRSZ + (incl & 0xFFFFu) - ml) << 16) | ((el >> 8) << 8) | (OTZ_K_LEN << 4);
+		}
+		if (md) {
+			L.dist_lut[tid] = ((DRSZ + (incl >> 16) - md) << 16) | ((ed >> 8) << 8) | (OTZ_K_LEN << 4);
+		}
+	}
+	otz_sync ();
+	if (!fits) {
+		return false;
+	}
+	if (l > root) {
+		u32 link = lut[rr & (rsz - 1u)];
 		u32 sb = (link >> 8) & 15u, base = link >> 16;
-		u32 e = LIT ? otz_mk_lit_entry (sorted[kk], ll) : otz_mk_dist_entry (sorted[kk], ll);
-		u32 step = 1u << (ll - ROOT);
-		for (u32 idx = rr >> ROOT; idx < (1u << sb); idx += step) {
+		for (u32 idx = rr >> root; idx < (1u << sb); idx += 1u << (l - root)) {
 			lut[base + idx] = e;
 		}
 	}
@@ -598,124 +581,91 @@ OTZ_DEV bool otz_fill_lut(otz_inflate_lds &L, u32 *lut, const otz_canon &c, cons
 	return true;
 }
 
-// Build both decode tables from L.ll[0..hlit+hdist). All work-items; returns
-// false (uniformly) on an over-subscribed set.
-OTZ_DEV bool otz_build_tables(otz_inflate_lds &L, u32 hlit, u32 hdist) {
-	u32 tid = otz_tid ();
-	if (tid < 32u) {
-		L.hist[tid] = 0;
-	}
-	otz_sync ();
-	for (u32 i = tid; i < hlit + hdist; i += OTZ_NT) {
-		u32 l = L.ll[i];
-		if (l) {
-			otz_lds_add (&L.hist[(i < hlit ? 0u : 16u) + l], 1u);
-		}
-	}
-	otz_sync ();
-	if (tid == 0) {
-		bool ok = otz_canon_build (L.lit_c, &L.hist[0]);
-		L.flag = ok ? 1u : 0u;
-	}
-	if (tid == 64u) {
-		bool ok = otz_canon_build (L.dist_c, &L.hist[16]);
-		L.first_rej = ok ? 1u : 0u;
-	}
-	otz_sync ();
-	bool ok = L.flag != 0u && L.first_rej != 0u;
-	if (!ok) {
-		return false;
-	}
-	if (otz_wave () == 0) {
-		otz_sort_syms (L.lit_c, L.ll, hlit, L.lit_sorted);
-	} else if (otz_wave () == 1) {
-		otz_sort_syms (L.dist_c, L.ll + hlit, hdist, L.dist_sorted);
-	}
-	otz_sync ();
-	bool fits = otz_fill_lut<OTZ_LIT_ROOT, OTZ_LIT_LUT, true> (L, L.lit_lut, L.lit_c, L.lit_sorted);
-	fits = otz_fill_lut<OTZ_DIST_ROOT, OTZ_DIST_LUT, false> (L, L.dist_lut, L.dist_c, L.dist_sorted) && fits;
-	return fits;
-}
-
 // ------------------------------------------------------------ block headers
 
-// Work-item 0: parse BFINAL/BTYPE and, for a dynamic block, HLIT/HDIST/HCLEN and
-// the code-length code lengths (ref deflate-dec.inc.c:613-627, :122-156).
+// Block header, every work-item for itself: BFINAL/BTYPE and, for a dynamic block,
+// HLIT/HDIST/HCLEN (ref deflate-dec.inc.c:613-627, :122-156) are read straight from the
+// staged bits, so the verdict and the fields are uniform without a broadcast.
+// Wavefront 0 also builds the 7-bit lookup table of the code-length code: lane s takes
+// symbol s (0..18), its 3-bit length sits at slot inv_order[s] of the header; ranks and
+// per-length counts come from ballots, canonical first codes from a 7-step recurrence
+// in registers; L.flag = 0 reports an over-subscribed set.
 // p = stage-relative bit position, avail = input bits left from p.
-OTZ_DEV void otz_parse_header_a(otz_inflate_lds &L, u32 p, u64 avail) {
-	otz_br r;
-	otz_br_init (r, L.stage_w, p);
-	otz_br_refill (r, L.stage_w);
-	if (avail < 3) {
-		otz_set_status (L, OZG_ST_BUF);
-		return;
+struct otz_hdr {
+	int st; // 0, or the status that ends the entry
+	u32 bfinal, btype, hlit, hdist, bits;
+};
+OTZ_DEV otz_hdr otz_parse_header_par(otz_inflate_lds &L, u32 p, u64 avail) {
+	otz_hdr H;
+	H.st = 0;
+	H.bfinal = H.btype = H.hlit = H.hdist = 0;
+	H.bits = 3;
+	const u32 w = p >> 5, sh = p & 31u;
+	const u32 d0 = L.stage_w[w], d1 = L.stage_w[w + 1u];
+	const u32 lo = otz_alignbit (d1, d0, sh);
+	if (avail < 3u) {
+		H.st = OZG_ST_BUF;
+		return H;
 	}
-	L.bfinal = (u32)r.bb & 1u;
-	L.btype = ((u32)r.bb >> 1) & 3u;
-	otz_br_drop (r, 3);
-	u32 used = 3;
-	if (L.btype == 3u) {
-		otz_set_status (L, OZG_ST_DATA);
-		return;
+	H.bfinal = lo & 1u;
+	H.btype = (lo >> 1) & 3u;
+	if (H.btype == 3u) {
+		H.st = OZG_ST_DATA;
+		return H;
 	}
-	if (L.btype == 2u) {
-		otz_br_refill (r, L.stage_w);
-		if (avail < used + 14u) {
-			otz_set_status (L, OZG_ST_DATA);
-			return;
-		}
-		u32 hlit = ((u32)r.bb & 31u) + 257u;
-		u32 hdist = (((u32)r.bb >> 5) & 31u) + 1u;
-		u32 hclen = (((u32)r.bb >> 10) & 15u) + 4u;
-		otz_br_drop (r, 14);
-		used += 14;
-		if (avail < used + 3u * hclen) {
-			otz_set_status (L, OZG_ST_DATA);
-			return;
-		}
-		const u8 order[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
-		for (u32 i = 0; i < 19; i++) {
-			L.cl_len[i] = 0;
-		}
-		for (u32 i = 0; i < hclen; i++) {
-			otz_br_refill (r, L.stage_w);
-			L.cl_len[order[i]] = (u8) ((u32)r.bb & 7u);
-			otz_br_drop (r, 3);
-		}
-		used += 3u * hclen;
-		L.hlit = hlit;
-		L.hdist = hdist;
-		// reference limit: LL_LENGTHS_MAX = 318 (:165-168); beyond it the
-		// reference reads outside ll_lengths[] -- fail cleanly instead
-		if (hlit + hdist > 318u) {
-			otz_set_status (L, OZG_ST_DATA);
-			return;
-		}
-		// code-length code: canonical bookkeeping
-		u32 hist[16];
-		for (u32 l = 0; l < 16; l++) {
-			hist[l] = 0;
-		}
-		for (u32 i = 0; i < 19; i++) {
-			hist[L.cl_len[i]]++;
-		}
-		hist[0] = 0;
-		if (!otz_canon_build (L.cl_c, hist)) {
-			otz_set_status (L, OZG_ST_DATA);
-			return;
-		}
-		u32 nxt[8];
-		for (u32 l = 0; l < 8; l++) {
-			nxt[l] = L.cl_c.off[l];
-		}
-		for (u32 i = 0; i < 19; i++) {
-			u32 l = L.cl_len[i];
-			if (l) {
-				L.cl_sorted[nxt[l]++] = (u8)i;
+	if (H.btype != 2u) {
+		return H;
+	}
+	H.hlit = ((lo >> 3) & 31u) + 257u;
+	H.hdist = ((lo >> 8) & 31u) + 1u;
+	const u32 hclen = ((lo >> 13) & 15u) + 4u;
+	H.bits = 17u + 3u * hclen;
+	// reference limit: LL_LENGTHS_MAX = 318 (:165-168); beyond it the reference reads
+	// outside ll_lengths[] -- fail cleanly instead
+	if (avail < H.bits || H.hlit + H.hdist > 318u) {
+		H.st = OZG_ST_DATA;
+		return H;
+	}
+	if (otz_wave () == 0) {
+		const u32 lane = otz_lane ();
+		L.cl_lut[lane] = 0;
+		L.cl_lut[lane + 64u] = 0;
+		otz_wave_sync ();
+		// slot of symbol s in the transmitted order 16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15 (5 bits each)
+		const u64 inv_lo = 3ull | (17ull << 5) | (15ull << 10) | (13ull << 15) | (11ull << 20) | (9ull << 25) | (7ull << 30) | (5ull << 35) |
+			(4ull << 40) | (6ull << 45) | (8ull << 50) | (10ull << 55);                                     // symbols 0..11
+		const u64 inv_hi = 12ull | (14ull << 5) | (16ull << 10) | (18ull << 15) | (0ull << 20) | (1ull << 25) | (2ull << 30); // symbols 12..18
+		u32 l = 0;
+		if (lane < 19u) {
+			u32 slot = (u32) ((lane < 12u ? inv_lo >> (5u * lane) : inv_hi >> (5u * (lane - 12u))) & 31u);
+			if (slot < hclen) {
+				u32 at = p + 17u + 3u * slot;
+				l = otz_alignbit (L.stage_w[(at >> 5) + 1u], L.stage_w[at >> 5], at & 31u) & 7u;
 			}
 		}
+		const u64 below = ((u64)1 << lane) - 1u;
+		u32 code = 0, kraft = 0, my_first = 0, rank = 0;
+		for (u32 k = 1; k <= 7u; k++) {
+			u64 m = otz_ballot (l == k);
+			u32 cnt = otz_popc64 (m);
+			if (l == k) {
+				my_first = code;
+				rank = otz_popc64 (m & below);
+			}
+			code = (code + cnt) << 1;
+			kraft += cnt << (7u - k);
+		}
+		if (l) {
+			u32 rr = otz_brev (my_first + rank) >> (32u - l);
+			for (u32 idx = rr; idx < 128u; idx += 1u << l) {
+				L.cl_lut[idx] = (lane << 8) | l;
+			}
+		}
+		if (lane == 0) {
+			L.flag = kraft <= 128u ? 1u : 0u;
+		}
 	}
-	L.hdr_bits = used;
+	return H;
 }
 
 // Every work-item calls this with the same st: the barriers keep the write to
@@ -752,12 +702,11 @@ OTZ_DEV u32 &otz_scr32(otz_inflate_lds &L, u32 scr, u32 i) {
 	return *reinterpret_cast<u32 *> (&L.ring[at]);
 }
 
-OTZ_DEV void otz_parse_lengths_par(otz_inflate_lds &L, u32 p, u64 avail, u32 scr) {
+OTZ_DEV void otz_parse_lengths_par(otz_inflate_lds &L, u32 p, u64 avail, u32 scr, u32 n) {
 	static_assert (OTZ_NT >= 320 && OTZ_NT >= OTZ_HP_HEADS * OTZ_HP_GROUP, "one work-item per code length / per token");
 	static_assert ((2u * OTZ_HP_NPOS + OTZ_HP_HEADS) * 4u <= OTZ_RMAX - 4u, "scratch fits the free ring region");
 	static_assert (OTZ_HP_NPOS % OTZ_NT == 0, "whole chunks");
 	const u32 tid = otz_tid ();
-	const u32 n = L.hlit + L.hdist;
 	// a chain that is still valid has spent at most 7 bits per length
 	const u32 npos = 7u * n + 16u < OTZ_HP_NPOS ? 7u * n + 16u : OTZ_HP_NPOS;
 	for (u32 i = tid; i < npos; i += OTZ_NT) {
@@ -1292,6 +1241,7 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 	u32 crc_reg = 0xFFFFFFFFu;
 	u32 flags = 0;
 	bool last_block = false, ended = false;
+	u32 last_btype = 0; // type of the block decoded last
 
 	{
 		// uniform start-up verdict; nobody reads L.status before the barrier
@@ -1312,7 +1262,6 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 			L.prof_last = otz_cycles ();
 			L.prof[OTZ_P_TOTAL] = 0 - L.prof_last;
 			L.eob_start_lo = L.eob_start_hi = 0;
-			L.btype = 0;
 		}
 		otz_sync ();
 	}
@@ -1329,18 +1278,18 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 		u32 p0 = skew * 8u + (u32) (abs_bit & 7u);
 		u64 stage_abs = abs_bit - p0; // absolute bit position of stage bit 0 (may wrap below zero; only sums are used)
 		OTZ_MARK (L, J, OTZ_P_STAGE);
-		if (tid == 0) {
-			otz_parse_header_a (L, p0, total_bits - abs_bit);
-		}
+		const otz_hdr H = otz_parse_header_par (L, p0, total_bits - abs_bit);
 		otz_sync ();
 		OTZ_MARK (L, J, OTZ_P_HEADER);
 		OTZ_COUNT (L, J, OTZ_P_BLOCKS, 1);
-		if (otz_get_status (L) != 0) {
+		if (H.st != 0 || (H.btype == 2u && L.flag == 0u)) {
+			otz_fail_all (L, H.st != 0 ? H.st : OZG_ST_DATA);
 			break;
 		}
-		last_block = L.bfinal != 0;
-		u32 btype = L.btype;
-		abs_bit += L.hdr_bits;
+		last_block = H.bfinal != 0;
+		const u32 btype = H.btype;
+		last_btype = btype;
+		abs_bit += H.bits;
 		if (btype == 0) {
 			// ---- stored block (ref read_uncompressed_block :269-319)
 			abs_bit = (abs_bit + 7u) & ~(u64)7u;
@@ -1384,25 +1333,17 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 			continue;
 		}
 		// ---- Huffman block: code lengths
+		u32 hlit = 288, hdist = 32;
 		if (btype == 1) {
 			for (u32 i = tid; i < 320u; i += OTZ_NT) {
 				L.ll[i] = (u8) (i <= 143u ? 8 : i <= 255u ? 9 : i <= 279u ? 7 : i <= 287u ? 8 : 5);
 			}
-			if (tid == 0) {
-				L.hlit = 288;
-				L.hdist = 32;
-			}
 			otz_sync ();
 		} else {
-			// 7-bit LUT of the code-length code, then the run-length coded lengths
-			if (tid < 128u) {
-				u32 l;
-				u32 k = otz_canon_lookup (L.cl_c, tid, 1, 7, &l);
-				L.cl_lut[tid] = l ? (((u32)L.cl_sorted[k] << 8) | l) : 0u;
-			}
-			const u32 lens_at = p0 + L.hdr_bits;
-			otz_sync ();
-			otz_parse_lengths_par (L, lens_at, total_bits - abs_bit, OTZ_RIDX ((opos + 3u) & ~3u));
+			// the run-length coded lengths, through the 7-bit LUT of the code-length code
+			hlit = H.hlit;
+			hdist = H.hdist;
+			otz_parse_lengths_par (L, p0 + H.bits, total_bits - abs_bit, OTZ_RIDX ((opos + 3u) & ~3u), hlit + hdist);
 			otz_sync ();
 			OTZ_MARK (L, J, OTZ_P_LENGTHS);
 			if (otz_get_status (L) != 0) {
@@ -1410,12 +1351,9 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 			}
 			abs_bit += L.hdr_bits;
 		}
-		{
-			u32 hlit = L.hlit, hdist = L.hdist;
-			if (!otz_build_tables (L, hlit, hdist)) {
-				otz_fail_all (L, OZG_ST_DATA);
-				break;
-			}
+		if (!otz_build_tables (L, hlit, hdist)) {
+			otz_fail_all (L, OZG_ST_DATA);
+			break;
 		}
 
 		otz_dec D;
@@ -1600,7 +1538,7 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 	if (status == 0) {
 		// ---- reached the end of the final block
 		status = OZG_ST_OK;
-		if (L.btype != 0) {
+		if (last_btype != 0) {
 			// the reference returns Z_BUF_ERROR when every input byte had
 			// already been loaded before the step that decodes the final EOB
 			u64 eob = ((u64)L.eob_start_hi << 32) | L.eob_start_lo;

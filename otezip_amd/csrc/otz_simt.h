@@ -100,6 +100,12 @@ OTZ_DEV void otz_st16u(void *p, u16 v) { __builtin_memcpy (p, &v, 2); }
 // Keeps the compiler from moving memory accesses across this point; emits nothing.  With
 // the in-order LDS pipeline that is all "flag, then data" needs (see otz_lds_load_inorder).
 OTZ_DEV void otz_order_loads() { asm volatile ("" ::: "memory"); }
+// Hides a value's origin from the optimiser: stops it from computing per-lane constants
+// once in the kernel prologue and keeping them alive (spilled) across everything else.
+OTZ_DEV u32 otz_opaque(u32 v) {
+	asm volatile ("" : "+v"(v));
+	return v;
+}
 
 // 16-byte global accesses.  gfx950 runs with unaligned global access enabled,
 // so an under-aligned source still lowers to one global_load_dwordx4.

@@ -123,6 +123,7 @@ OTZ_DEV void otz_st64u(void *p, u64 v) { memcpy (p, &v, 8); }
 OTZ_DEV void otz_st32u(void *p, u32 v) { memcpy (p, &v, 4); }
 OTZ_DEV void otz_st16u(void *p, u16 v) { memcpy (p, &v, 2); }
 OTZ_DEV void otz_order_loads() { __atomic_thread_fence (__ATOMIC_ACQUIRE); }
+OTZ_DEV u32 otz_opaque(u32 v) { return v; }
 
 OTZ_DEV otz_u4 otz_ld16(const void *p) {
 	otz_u4 v;

@@ -11,7 +11,7 @@ import torch
 import otezip_amd as oz
 from otezip_amd import corpus, _native as N
 
-NAMES = ["header", "lengths", "tables", "stage", "passA", "passB", "scan", "place", "flush", "stored", "resolve", "-",
+NAMES = ["header", "lengths", "tables", "stage", "passA", "passB", "scan", "place", "flush", "stored", "resolve", "aux11",
          "rounds#", "B_iters#", "blocks#", "total"]
 
 
