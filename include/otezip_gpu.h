@@ -127,8 +127,11 @@ typedef struct ozg_enc_entry {
 	uint32_t dst_cap;  /* >= ozg_compress_bound(method, src_size) */
 	uint16_t method;   /* requested method (what za->default_method holds) */
 	uint16_t level;    /* ignored: the reference always runs its default level (ref :826) */
-	uint32_t reserved;
+	uint32_t reserved; /* 0, or OZG_ENC_F_* */
 } ozg_enc_entry;
+/* codec-level call (the deflate() of the z_stream seam): always write the requested method,
+ * never fall back to STORE; OZG_ST_BUF if dst_cap is too small.  DEFLATE only. */
+#define OZG_ENC_F_CODEC_ONLY 1u
 
 /* 16 bytes */
 typedef struct ozg_enc_result {

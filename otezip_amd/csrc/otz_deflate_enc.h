@@ -394,10 +394,35 @@ OTZ_DEV void otz_encode_entry(otz_enc_lds &L, const u8 *src, u8 *dst, const ozg_
 	const u8 *in = src + e.src_off;
 	u8 *out = dst + e.dst_off;
 	bool stored = true;
-	if (((uintptr_t)out & 15u) != 0 || e.dst_cap < e.src_size) {
+	const bool codec_only = e.method == OZG_METHOD_DEFLATE && (e.reserved & OZG_ENC_F_CODEC_ONLY);
+	if (((uintptr_t)out & 15u) != 0 || (e.dst_cap < e.src_size && !codec_only)) {
 		if (lane == 0) {
 			res->status = OZG_ST_INTERNAL;
 			res->comp_size = 0;
+			res->method = e.method;
+			res->flags = 0;
+		}
+		return;
+	}
+	if (codec_only) {
+		// codec-level call (deflate() of the z_stream seam): the stream itself is the
+		// product, there is no "not smaller -> STORE" rule at this level (ref deflate() has none)
+		u32 cs;
+		if (e.src_size > 0) {
+			cs = otz_deflate_entry (L, in, e.src_size, out, e.dst_cap);
+		} else {
+			cs = 5; // an empty final stored block
+			if (lane == 0 && e.dst_cap >= 5u) {
+				out[0] = 1;
+				out[1] = out[2] = 0;
+				out[3] = out[4] = 0xFF;
+			}
+		}
+		otz_wave_sync ();
+		if (lane == 0) {
+			bool fit = cs <= e.dst_cap;
+			res->status = fit ? OZG_ST_OK : OZG_ST_BUF;
+			res->comp_size = fit ? cs : 0;
 			res->method = e.method;
 			res->flags = 0;
 		}

@@ -368,7 +368,8 @@ int ozg_encode_batch_host(const void *src, uint64_t src_len, void *dst, uint64_t
 	}
 	for (uint32_t i = 0; i < n; i++) {
 		const ozg_enc_entry &e = entries[i];
-		if (e.src_off + e.src_size > src_len || (e.dst_off & 15u) || e.dst_off + e.dst_cap > dst_len || e.dst_cap < e.src_size) {
+		const bool codec_only = e.method == OZG_METHOD_DEFLATE && (e.reserved & OZG_ENC_F_CODEC_ONLY);
+		if (e.src_off + e.src_size > src_len || (e.dst_off & 15u) || e.dst_off + e.dst_cap > dst_len || (e.dst_cap < e.src_size && !codec_only)) {
 			snprintf (g_err, sizeof (g_err), "encode entry %u: offsets outside the buffers, dst_off not a multiple of 16, or dst_cap < src_size", i);
 			return OZG_E_ARG;
 		}
