@@ -668,6 +668,18 @@ OTZ_DEV otz_hdr otz_parse_header_par(otz_inflate_lds &L, u32 p, u64 avail) {
 	return H;
 }
 
+// *p = min (*p, lowest work-item id of this wavefront for which pred holds): one ballot and
+// at most one LDS atomic per wavefront.  (A per-lane atomic min is serialised by the
+// compiler into a loop over the active lanes.)  Wavefront-uniform control flow only.
+OTZ_DEV void otz_wave_min_tid(u32 *p, bool pred) {
+	const u64 m = otz_ballot (pred);
+	const u32 lo = (u32)m, hi = (u32) (m >> 32);
+	const u32 first = lo ? otz_ctz (lo) : 32u + otz_ctz (hi | 0x80000000u);
+	if (m != 0 && otz_lane () == first) {
+		otz_lds_min (p, otz_tid ());
+	}
+}
+
 // Every work-item calls this with the same st: the barriers keep the write to
 // L.status away from work-items that are still reading it.
 OTZ_DEV void otz_fail_all(otz_inflate_lds &L, int st) {
@@ -1414,6 +1426,7 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 				if (tid == 0) {
 					L.bmin[slot ^ 1u][0] = L.bmin[slot ^ 1u][1] = OTZ_NT;
 				}
+				bool changed = false;
 				if (tid && OTZ_X_KIND (prev) == OTZ_X_NORMAL && OTZ_X_POS (prev) != t) {
 					t = OTZ_X_POS (prev);
 					otz_path B = otz_walk<OTZ_MODE_B> (L, D, t, s, e, limit_bits, 0, vis);
@@ -1423,12 +1436,11 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 					if (ne != my_exit) {
 						my_exit = ne;
 						L.exits[tid] = ne;
-						otz_lds_min (&L.bmin[slot][0], tid);
+						changed = true;
 					}
 				}
-				if (OTZ_X_KIND (my_exit) != OTZ_X_NORMAL) {
-					otz_lds_min (&L.bmin[slot][1], tid);
-				}
+				otz_wave_min_tid (&L.bmin[slot][0], changed);
+				otz_wave_min_tid (&L.bmin[slot][1], OTZ_X_KIND (my_exit) != OTZ_X_NORMAL);
 				otz_sync ();
 				OTZ_COUNT (L, J, OTZ_P_B_ITERS, 1);
 				u32 first_changed = L.bmin[slot][0], first_term = L.bmin[slot][1];
@@ -1457,17 +1469,13 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 					bytes = wbytes + A.bytes - pre;
 				}
 			}
-			if (OTZ_X_KIND (my_exit) != OTZ_X_NORMAL) {
-				otz_lds_min (&L.first_term, tid);
-			}
+			otz_wave_min_tid (&L.first_term, OTZ_X_KIND (my_exit) != OTZ_X_NORMAL);
 			u32 total;
 			u32 incl = otz_block_scan_incl (bytes, L.scan, &total);
 			const u32 F = L.first_term; // first lane whose path terminates; lanes <= F are the true chain
 			bool onchain = tid <= F;
 			bool acc = onchain && incl <= limit;
-			if (!acc) {
-				otz_lds_min (&L.first_rej, tid);
-			}
+			otz_wave_min_tid (&L.first_rej, !acc);
 			otz_sync ();
 			const u32 K = L.first_rej; // lanes [0, K) are materialised this round
 			if (tid == K && onchain) {
