@@ -880,6 +880,7 @@ struct otz_path {
 // round's own not-yet-written output region, which is free until placement.  `notes`
 // points at the lane's record; note_cap is 0 for the one lane whose record would
 // straddle the end of the ring (it falls back to re-walking its prefix).
+#define OTZ_WARM_BITS 64u // pass A's head start (must stay below OTZ_S_BITS: lane 1 starts inside the stage)
 #define OTZ_CUM_CAP 23u
 #define OTZ_CUM_STRIDE (2u * OTZ_CUM_CAP)
 
@@ -897,7 +898,10 @@ OTZ_DEV otz_path otz_walk(otz_inflate_lds &L, const otz_dec &D, u32 start, u32 s
 	otz_win_init (W, L, pos);
 	while (pos < end) {
 		const u32 rel = pos - s; // pos >= s always (a left neighbour exits at or after s)
-		if (MODE == OTZ_MODE_A) {
+		// MODE_A may start before s (warm-up, see pass A): those tokens are neither
+		// recorded nor counted
+		const bool counted = MODE != OTZ_MODE_A || pos >= s;
+		if (MODE == OTZ_MODE_A && counted) {
 			otz_vis_set (vis, rel);
 			if (ntok < note_cap) {
 				notes[ntok] = (u16)bytes;
@@ -924,8 +928,10 @@ OTZ_DEV otz_path otz_walk(otz_inflate_lds &L, const otz_dec &D, u32 start, u32 s
 			break;
 		}
 		pos = npos;
-		ntok++;
-		bytes += t.kind == OTZ_K_LIT ? 1u : t.val;
+		if (counted) {
+			ntok++;
+			bytes += t.kind == OTZ_K_LIT ? 1u : t.val;
+		}
 	}
 	P.exit = OTZ_X_MAKE (xk, pos);
 	P.bytes = bytes;
@@ -1402,7 +1408,12 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 			const u32 note_at = OTZ_RIDX (((opos + 1u) & ~1u) + tid * OTZ_CUM_STRIDE);
 			u16 *const notes = reinterpret_cast<u16 *> (&L.ring[note_at]);
 			const u32 note_cap = note_at + OTZ_CUM_STRIDE <= OTZ_RING ? OTZ_CUM_CAP : 0u;
-			otz_path A = otz_walk<OTZ_MODE_A> (L, D, s, s, e, limit_bits, 0, vis, notes, note_cap);
+			// Lanes other than 0 start OTZ_WARM_BITS early: a Huffman stream decoded from a
+			// wrong bit position falls into step with the real token chain after a few
+			// tokens, so by the time the path reaches s it is usually already the true
+			// one, and pass B's walk meets it at its first token.
+			const u32 a_start = tid ? s - OTZ_WARM_BITS : s;
+			otz_path A = otz_walk<OTZ_MODE_A> (L, D, a_start, s, e, limit_bits, 0, vis, notes, note_cap);
 			L.exits[tid] = A.exit;
 			otz_sync ();
 
@@ -1462,8 +1473,10 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 						if (ord < note_cap) {
 							pre = notes[ord];
 						} else {
+							// re-walk pass A's recorded path from its first token
 							otz_vis dummy = { 0, 0 };
-							pre = otz_walk<OTZ_MODE_PREFIX> (L, D, s, s, e, limit_bits, q, dummy).bytes;
+							const u32 first = s + (vis.lo ? otz_ctz64 (vis.lo) : 64u + otz_ctz64 (vis.hi));
+							pre = otz_walk<OTZ_MODE_PREFIX> (L, D, first, s, e, limit_bits, q, dummy).bytes;
 						}
 					}
 					bytes = wbytes + A.bytes - pre;

@@ -76,6 +76,7 @@ OTZ_DEV u32 otz_popc(u32 v) { return (u32)__popc (v); }
 OTZ_DEV u32 otz_popc64(u64 v) { return (u32)__popcll (v); }
 OTZ_DEV u32 otz_brev(u32 v) { return __brev (v); }
 OTZ_DEV u32 otz_ctz(u32 v) { return (u32)__builtin_ctz (v); }
+OTZ_DEV u32 otz_ctz64(u64 v) { return (u32)__builtin_ctzll (v); }
 // width (<32) bits of v starting at bit off: v_bfe_u32
 OTZ_DEV u32 otz_bfe(u32 v, u32 off, u32 width) { return __builtin_amdgcn_ubfe (v, off, width); }
 // low 32 bits of (hi:lo) >> (sh & 31): v_alignbit_b32

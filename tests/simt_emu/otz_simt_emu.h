@@ -106,6 +106,7 @@ OTZ_DEV u32 otz_brev(u32 v) {
 	return __builtin_bswap32 (v);
 }
 OTZ_DEV u32 otz_ctz(u32 v) { return (u32)__builtin_ctz (v); }
+OTZ_DEV u32 otz_ctz64(u64 v) { return (u32)__builtin_ctzll (v); }
 OTZ_DEV u32 otz_bfe(u32 v, u32 off, u32 width) { return (v >> (off & 31u)) & ((1u << (width & 31u)) - 1u); }
 OTZ_DEV u32 otz_alignbit(u32 hi, u32 lo, u32 sh) { return (u32) ((((u64)hi << 32) | lo) >> (sh & 31u)); }
 
