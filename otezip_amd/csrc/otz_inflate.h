@@ -1430,6 +1430,7 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 			if (tid == 0) {
 				L.bmin[0][0] = L.bmin[0][1] = OTZ_NT;
 			}
+			otz_set_priority_high ();
 			for (u32 it = 0; it <= OTZ_NT; it++) {
 				u32 slot = it & 1u;
 				u32 prev = tid ? L.exits[tid - 1] : 0u;
@@ -1459,6 +1460,7 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 					break;
 				}
 			}
+			otz_set_priority_normal ();
 			OTZ_MARK (L, J, OTZ_P_PASS_B);
 			// output bytes of this lane's true path
 			u32 bytes = 0;

@@ -71,6 +71,11 @@ OTZ_DEV void otz_lds_store(u32 *p, u32 v) { __hip_atomic_store (p, v, __ATOMIC_R
 OTZ_DEV void otz_fence_release() { __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup"); }
 OTZ_DEV void otz_fence_acquire() { __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup"); }
 OTZ_DEV void otz_backoff() { __builtin_amdgcn_s_sleep (2); }
+// Issue priority of this wavefront (0 = default .. 3): raised around dependency-bound phases
+// so that the few wavefronts on the critical path are not queued behind the bulk work of
+// the other workgroup on the CU.
+OTZ_DEV void otz_set_priority_high() { __builtin_amdgcn_s_setprio (2); }
+OTZ_DEV void otz_set_priority_normal() { __builtin_amdgcn_s_setprio (0); }
 
 OTZ_DEV u32 otz_popc(u32 v) { return (u32)__popc (v); }
 OTZ_DEV u32 otz_popc64(u64 v) { return (u32)__popcll (v); }

@@ -96,6 +96,8 @@ OTZ_DEV void otz_lds_store(u32 *p, u32 v) { __atomic_store_n (p, v, __ATOMIC_REL
 OTZ_DEV void otz_fence_release() { __atomic_thread_fence (__ATOMIC_RELEASE); }
 OTZ_DEV void otz_fence_acquire() { __atomic_thread_fence (__ATOMIC_ACQUIRE); }
 OTZ_DEV void otz_backoff() { sched_yield (); }
+OTZ_DEV void otz_set_priority_high() {}
+OTZ_DEV void otz_set_priority_normal() {}
 
 OTZ_DEV u32 otz_popc(u32 v) { return (u32)__builtin_popcount (v); }
 OTZ_DEV u32 otz_popc64(u64 v) { return (u32)__builtin_popcountll (v); }
