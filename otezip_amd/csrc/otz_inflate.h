@@ -221,12 +221,18 @@ struct otz_dec {
 };
 OTZ_DEV void otz_dec_load(otz_dec &D, const otz_inflate_lds &L) { D.unused = 0; }
 
+// Table entries: code length in bits 0-3, OTZ_K_* in bits 4-5, extra-bit count in bits
+// 8-11, value (literal, length base, distance base) in bits 16+.  A slot no code maps to is
+// OTZ_LUT_NONE (kind BAD, length 0); a root slot whose codes are longer than the root is a
+// link (OTZ_LUT_LINK, the sign bit).
+#define OTZ_LUT_NONE (OTZ_K_BAD << 4)
+#define OTZ_LUT_LINK 0x80000000u
 // root lookup, then at most one sub-table lookup
 template <u32 ROOT>
 OTZ_DEV u32 otz_lut2(const u32 *lut, u32 bits) {
 	u32 e = lut[bits & ((1u << ROOT) - 1u)];
-	if ((e & 0x3Fu) == (OTZ_K_LEN << 4)) {
-		e = lut[(e >> 16) + otz_bfe (bits, ROOT, (e >> 8) & 15u)];
+	if ((int)e < 0) { // OTZ_LUT_LINK: sub-table base in bits 16-30, index width in bits 8-11
+		e = lut[((e >> 16) & 0x7FFFu) + otz_bfe (bits, ROOT, (e >> 8) & 15u)];
 	}
 	return e;
 }
@@ -239,7 +245,7 @@ OTZ_DEV otz_tok otz_decode_bits(const otz_inflate_lds &L, u32 lo, u32 hi) {
 	otz_tok t;
 	u32 e = otz_lut2<OTZ_LIT_ROOT> (L.lit_lut, lo);
 	u32 len = e & 15u;
-	t.kind = len ? (e >> 4) & 3u : OTZ_K_BAD;
+	t.kind = (e >> 4) & 3u;
 	t.val = e >> 16;
 	t.dist = 0;
 	t.nbits = len;
@@ -252,7 +258,7 @@ OTZ_DEV otz_tok otz_decode_bits(const otz_inflate_lds &L, u32 lo, u32 hi) {
 	u32 db = otz_alignbit (hi, lo, used);
 	u32 d = otz_lut2<OTZ_DIST_ROOT> (L.dist_lut, db);
 	u32 dl = d & 15u, dxb = (d >> 8) & 15u; // dl + dxb <= 28
-	if (dl == 0 || ((d >> 4) & 3u) != OTZ_K_LEN) {
+	if (((d >> 4) & 3u) != OTZ_K_LEN) {
 		t.kind = OTZ_K_BAD;
 		t.nbits = 0;
 		return t;
@@ -473,10 +479,10 @@ OTZ_DEV bool otz_build_tables(otz_inflate_lds &L, u32 hlit, u32 hdist) {
 		l = L.ll[hlit + sym];
 	}
 	for (u32 i = tid; i < OTZ_LIT_LUT; i += OTZ_NT) {
-		L.lit_lut[i] = 0;
+		L.lit_lut[i] = OTZ_LUT_NONE;
 	}
 	for (u32 i = tid; i < OTZ_DIST_LUT; i += OTZ_NT) {
-		L.dist_lut[i] = 0;
+		L.dist_lut[i] = OTZ_LUT_NONE;
 	}
 	u32 rank = 0; // symbols of the same length before this one in its wavefront
 	if (wave < 6u) {
@@ -553,17 +559,18 @@ OTZ_DEV bool otz_build_tables(otz_inflate_lds &L, u32 hlit, u32 hdist) {
 	// sub-table placement: one prefix sum over the root slots of both tables (literal
 	// sizes in the low half of the scanned word, distance sizes in the high half)
 	u32 el = L.lit_lut[tid < LRSZ ? tid : 0u], ed = L.dist_lut[tid < DRSZ ? tid : 0u];
-	u32 ml = tid < LRSZ && el && (el & 15u) == 0 ? 1u << (el >> 8) : 0u;
-	u32 md = tid < DRSZ && ed && (ed & 15u) == 0 ? 1u << (ed >> 8) : 0u;
+	// a root slot claimed by longer codes holds (widest code - root) << 8 at this point
+	u32 ml = tid < LRSZ && el && (el & 0xFFu) == 0 ? 1u << (el >> 8) : 0u;
+	u32 md = tid < DRSZ && ed && (ed & 0xFFu) == 0 ? 1u << (ed >> 8) : 0u;
 	u32 total;
 	u32 incl = otz_block_scan_incl (ml | (md << 16), L.scan, &total);
 	const bool fits = (total & 0xFFFFu) <= OTZ_LIT_LUT - LRSZ && (total >> 16) <= OTZ_DIST_LUT - DRSZ;
 	if (fits) {
 		if (ml) {
-			L.lit_lut[tid] = ((LRSZ + (incl & 0xFFFFu) - ml) << 16) | ((el >> 8) << 8) | (OTZ_K_LEN << 4);
+			L.lit_lut[tid] = OTZ_LUT_LINK | ((LRSZ + (incl & 0xFFFFu) - ml) << 16) | ((el >> 8) << 8) | OTZ_LUT_NONE;
 		}
 		if (md) {
-			L.dist_lut[tid] = ((DRSZ + (incl >> 16) - md) << 16) | ((ed >> 8) << 8) | (OTZ_K_LEN << 4);
+			L.dist_lut[tid] = OTZ_LUT_LINK | ((DRSZ + (incl >> 16) - md) << 16) | ((ed >> 8) << 8) | OTZ_LUT_NONE;
 		}
 	}
 	otz_sync ();
@@ -572,7 +579,7 @@ OTZ_DEV bool otz_build_tables(otz_inflate_lds &L, u32 hlit, u32 hdist) {
 	}
 	if (l > root) {
 		u32 link = lut[rr & (rsz - 1u)];
-		u32 sb = (link >> 8) & 15u, base = link >> 16;
+		u32 sb = (link >> 8) & 15u, base = (link >> 16) & 0x7FFFu;
 		for (u32 idx = rr >> root; idx < (1u << sb); idx += 1u << (l - root)) {
 			lut[base + idx] = e;
 		}
