@@ -897,14 +897,18 @@ struct otz_path {
 template <int MODE>
 OTZ_DEV otz_path otz_walk(otz_inflate_lds &L, const otz_dec &D, u32 start, u32 s, u32 e, u32 limit_bits, u32 stop, otz_vis &vis, u16 *notes = nullptr, u32 note_cap = 0) {
 	otz_path P;
-	P.syncq = ~0u;
 	u32 pos = start, ntok = 0, bytes = 0;
-	u32 xk = OTZ_X_NORMAL;
 	const u32 end = MODE == OTZ_MODE_PREFIX ? stop : e;
+	// The loop body is straight-line: ONE condition keeps a lane in the loop, everything
+	// else is a select.  (Several `break`s cost more scalar mask bookkeeping per step than
+	// the decode itself.)  A lane that stops this step still decodes its token -- it leaves
+	// the loop right after, so that costs the wavefront nothing.
+	bool stopped = false, hit = false;
+	u32 last_kind = OTZ_K_LIT, last_end = 0;
 	otz_win W;
 	otz_win_init (W, L, pos);
-	while (pos < end) {
-		const u32 rel = pos - s; // pos >= s always (a left neighbour exits at or after s)
+	while (pos < end && !stopped) {
+		const u32 rel = pos - s; // MODE_B/PREFIX: pos >= s always (a left neighbour exits at or after s)
 		// MODE_A may start before s (warm-up, see pass A): those tokens are neither
 		// recorded nor counted
 		const bool counted = MODE != OTZ_MODE_A || pos >= s;
@@ -915,29 +919,29 @@ OTZ_DEV otz_path otz_walk(otz_inflate_lds &L, const otz_dec &D, u32 start, u32 s
 			}
 		}
 		if (MODE == OTZ_MODE_B) {
-			if (otz_vis_test (vis, rel)) {
-				P.syncq = pos;
-				break;
-			}
+			hit = otz_vis_test (vis, rel);
 		}
 		const otz_tok t = otz_decode_adv (L, W, pos);
-		const u32 npos = pos + t.nbits;
-		if (t.kind >= OTZ_K_EOB || npos > limit_bits) {
-			// the rare ways out; pos stays at the token's start except after an end-of-block code
-			if (t.kind == OTZ_K_BAD) {
-				xk = pos >= limit_bits ? OTZ_X_TRUNC : OTZ_X_INVALID;
-			} else if (npos > limit_bits) {
-				xk = OTZ_X_TRUNC;
-			} else {
-				xk = OTZ_X_EOB;
-				pos = npos;
-			}
-			break;
-		}
-		pos = npos;
-		if (counted) {
-			ntok++;
-			bytes += t.kind == OTZ_K_LIT ? 1u : t.val;
+		last_kind = t.kind;
+		last_end = pos + t.nbits;
+		stopped = hit || t.kind >= OTZ_K_EOB || last_end > limit_bits;
+		pos = stopped ? pos : last_end;
+		const bool adv = counted && !stopped;
+		ntok += adv ? 1u : 0u;
+		bytes += adv ? (t.kind == OTZ_K_LIT ? 1u : t.val) : 0u;
+	}
+	// how the walk ended; pos is the start of the token it stopped at, or the first token start
+	// at or beyond `end`
+	u32 xk = OTZ_X_NORMAL;
+	P.syncq = hit ? pos : ~0u;
+	if (stopped && !hit) {
+		if (last_kind == OTZ_K_BAD) {
+			xk = pos >= limit_bits ? OTZ_X_TRUNC : OTZ_X_INVALID;
+		} else if (last_end > limit_bits) {
+			xk = OTZ_X_TRUNC;
+		} else {
+			xk = OTZ_X_EOB; // position just after the end-of-block code
+			pos = last_end;
 		}
 	}
 	P.exit = OTZ_X_MAKE (xk, pos);
