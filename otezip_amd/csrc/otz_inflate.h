@@ -1007,17 +1007,19 @@ OTZ_DEV void otz_place(otz_inflate_lds &L, const otz_dec &D, bool active, u32 st
 	// before the barrier after this pass, so no ordering is needed.
 	u32 curw = rel >> 5, finm = 0, stm = 0;
 	u32 kind = OTZ_K_LIT, tpos = pos, tbits = 0;
+	bool stopped = false, too_far = false;
 	otz_win W;
 	otz_win_init (W, L, pos);
-	while (pos < exit_pos) {
+	// straight-line body, one loop condition (see otz_walk)
+	while (pos < exit_pos && !stopped) {
 		const otz_tok t = otz_decode_adv (L, W, pos);
 		kind = t.kind;
 		tpos = pos;
 		tbits = t.nbits;
-		if (kind >= OTZ_K_EOB) {
-			break;
-		}
-		pos += t.nbits;
+		const bool lit = kind == OTZ_K_LIT;
+		// ref reads window bytes nobody wrote (:524): no parity, fail cleanly
+		too_far = kind == OTZ_K_LEN && t.dist > round_base + rel;
+		stopped = kind >= OTZ_K_EOB || too_far;
 		const u32 w = rel >> 5;
 		if (w != curw) {
 			if (finm) {
@@ -1029,26 +1031,24 @@ OTZ_DEV void otz_place(otz_inflate_lds &L, const otz_dec &D, bool active, u32 st
 			curw = w;
 			finm = stm = 0;
 		}
-		const u32 bit = 1u << (rel & 31u);
-		if (kind == OTZ_K_LIT) {
-			L.ring[ri] = (u8)t.val;
-			finm |= bit;
-			rel++;
-			ri = OTZ_RWRAP (ri + 1u);
-			continue;
+		if (!stopped) {
+			const u32 bit = 1u << (rel & 31u);
+			const u32 d = (t.dist - 1u) | ((t.val - 3u) << 15); // the parked match
+			L.ring[ri] = (u8) (lit ? t.val : d);
+			if (!lit) {
+				L.ring[OTZ_RWRAP (ri + 1u)] = (u8) (d >> 8);
+				L.ring[OTZ_RWRAP (ri + 2u)] = (u8) (d >> 16);
+			}
+			finm |= lit ? bit : 0u;
+			stm |= lit ? 0u : bit;
+			const u32 adv = lit ? 1u : t.val;
+			rel += adv;
+			ri = OTZ_RWRAP (ri + adv);
+			pos += t.nbits;
 		}
-		if (t.dist > round_base + rel) {
-			// ref reads window bytes nobody wrote (:524): no parity, fail cleanly
-			otz_set_status (L, OZG_ST_DATA);
-			break;
-		}
-		const u32 d = (t.dist - 1u) | ((t.val - 3u) << 15);
-		L.ring[ri] = (u8)d;
-		L.ring[OTZ_RWRAP (ri + 1u)] = (u8) (d >> 8);
-		L.ring[OTZ_RWRAP (ri + 2u)] = (u8) (d >> 16);
-		stm |= bit;
-		rel += t.val;
-		ri = OTZ_RWRAP (ri + t.val);
+	}
+	if (too_far) {
+		otz_set_status (L, OZG_ST_DATA);
 	}
 	if (finm) {
 		otz_lds_or (&L.fin[curw], finm);
