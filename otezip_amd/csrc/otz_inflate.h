@@ -1390,17 +1390,26 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 		OTZ_MARK (L, J, OTZ_P_TABLES);
 		// ---- rounds over the block's symbols
 		bool block_done = false;
+		// The bytes staged for the block header are still there (nothing has flushed since:
+		// the room was made before the header): the block's first round reuses them when
+		// a whole round still fits behind the header.
+		bool staged = true;
 		while (!block_done) {
 			u32 room = J.out_cap - opos;
 			u32 limit = room < OTZ_RMAX ? room : OTZ_RMAX;
 			// a full OTZ_RMAX is freed even near the end of the output: passes A/B use
 			// the round's output region as scratch
 			otz_make_room (L, J, opos, OTZ_RMAX, flushed, crc_reg);
-			byte0 = (u32) (abs_bit >> 3);
-			otz_sync ();
-			skew = otz_stage_load (L, J, byte0);
-			p0 = skew * 8u + (u32) (abs_bit & 7u);
-			stage_abs = abs_bit - p0;
+			if (staged && abs_bit - stage_abs + OTZ_NT * OTZ_S_BITS + 8u * 128u <= 8u * OTZ_STAGE_BYTES) {
+				p0 = (u32) (abs_bit - stage_abs);
+			} else {
+				byte0 = (u32) (abs_bit >> 3);
+				otz_sync ();
+				skew = otz_stage_load (L, J, byte0);
+				p0 = skew * 8u + (u32) (abs_bit & 7u);
+				stage_abs = abs_bit - p0;
+			}
+			staged = false;
 			u64 lb = total_bits - stage_abs; // input ends at this stage-relative bit
 			u32 limit_bits = lb > 0xFFFFFFu ? 0xFFFFFFu : (u32)lb;
 			if (tid == 0) {
