@@ -4,6 +4,7 @@
 #ifndef OTEZIP_ZSTREAM_H
 #define OTEZIP_ZSTREAM_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 typedef unsigned char Bytef;
@@ -41,11 +42,11 @@ typedef z_stream *z_streamp;
 #define Z_DEFLATED 8
 #define MAX_WBITS 15
 
-/* The DEFLATE codec seam (ref src/lib/deflate.inc.c:89-97).  One call of inflate() /
- * deflate() processes next_in[0, avail_in) into next_out[0, avail_out) on the GPU batch path
- * (a batch of one); see otezip_amd/csrc/zstream_api.c for the contract.  The container
- * codecs' z_stream entry points (zstd*, lzfse*, brotli*, lzma*) are not exported yet:
- * those methods are reached through zip_fopen_index / zip_file_add. */
+/* The codec seam (ref src/lib/deflate.inc.c:89-97, zstd.inc.c:135-148, lzfse.inc.c:46-47 and
+ * :272-372, brotli.inc.c:82-214, lzma-enc.inc.c:92-98, lzma-dec.inc.c:84-90).  One call of
+ * inflate() / deflate() / <codec>Compress() / <codec>Decompress() processes next_in[0, avail_in)
+ * into next_out[0, avail_out) on the GPU batch path (a batch of one); see
+ * otezip_amd/csrc/zstream_api.c for the contract. */
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -57,6 +58,24 @@ int deflateInit2(z_stream *strm, int level, int method, int windowBits, int memL
 int deflateInit2_(z_stream *strm, int level, int method, int windowBits, int memLevel, int strategy, const char *version, int stream_size);
 int deflate(z_stream *strm, int flush);
 int deflateEnd(z_stream *strm);
+
+#define OTEZIP_CODEC_DECLS(name) \
+	int name##Init(z_stream *strm, int level); \
+	int name##Compress(z_stream *strm, int flush); \
+	int name##End(z_stream *strm); \
+	int name##DecompressInit(z_stream *strm); \
+	int name##Decompress(z_stream *strm, int flush); \
+	int name##DecompressEnd(z_stream *strm); \
+	int name##CompressInit2(z_stream *strm, int level, int windowBits, int memLevel, int strategy); \
+	int name##CompressInit2_(z_stream *strm, int level, int windowBits, int memLevel, int strategy, const char *version, int stream_size); \
+	int name##DecompressInit2(z_stream *strm, int windowBits); \
+	int name##DecompressInit2_(z_stream *strm, int windowBits, const char *version, int stream_size);
+OTEZIP_CODEC_DECLS (zstd)
+OTEZIP_CODEC_DECLS (lzfse)
+OTEZIP_CODEC_DECLS (brotli)
+OTEZIP_CODEC_DECLS (lzma)
+size_t lzfse_compress(const void *in, size_t in_sz, void *out, size_t out_cap);
+size_t lzfse_decompress(const void *in, size_t in_sz, void *out, size_t out_cap);
 #ifdef __cplusplus
 }
 #endif

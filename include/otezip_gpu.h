@@ -129,8 +129,9 @@ typedef struct ozg_enc_entry {
 	uint16_t level;    /* ignored: the reference always runs its default level (ref :826) */
 	uint32_t reserved; /* 0, or OZG_ENC_F_* */
 } ozg_enc_entry;
-/* codec-level call (the deflate() of the z_stream seam): always write the requested method,
- * never fall back to STORE; OZG_ST_BUF if dst_cap is too small.  DEFLATE only. */
+/* codec-level call (the <codec>Compress() of the z_stream seam): always write the requested
+ * method -- DEFLATE, or the reference's private 93 / 100 / 97 / 14 framings, byte-exact --
+ * never fall back to STORE; OZG_ST_BUF if dst_cap is too small. */
 #define OZG_ENC_F_CODEC_ONLY 1u
 
 /* 16 bytes */

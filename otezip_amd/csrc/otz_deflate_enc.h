@@ -291,7 +291,7 @@ OTZ_DEV u32 otz_lzma_emit_run(u8 *out, u32 op, u32 cap, u32 byte, u32 len, bool 
 	return op;
 }
 
-OTZ_DEV u32 otz_lzma_tok_entry(const u8 *in, u32 n, u8 *out, u32 cap) {
+OTZ_DEV u32 otz_lzma_tok_entry(const u8 *in, u32 n, u8 *out, u32 cap, bool keep_going = false) {
 	const u32 lane = otz_tid ();
 	if (cap < 13u) {
 		return ~0u;
@@ -369,7 +369,7 @@ OTZ_DEV u32 otz_lzma_tok_entry(const u8 *in, u32 n, u8 *out, u32 cap) {
 				carry_byte = otz_shfl (b, last);
 				carry_len = nvalid - last;
 			}
-			if (op >= n) {
+			if (op >= n && !keep_going) {
 				return ~0u; // can no longer be smaller than the input: STORE (ref otezip.c:1006-1011)
 			}
 		}
@@ -389,12 +389,78 @@ OTZ_DEV u32 otz_lzma_tok_entry(const u8 *in, u32 n, u8 *out, u32 cap) {
 //  * method 14: the private RLE tokens above, byte-exact, same fallback rule (:1006-1011)
 //  * zero-length input -> STORE with size 0 (:793-801)
 // The CRC-32 of the input (ref :1124) is taken by otz_enc_crc_kernel.
+// ------------------------------------------------- methods 93 / 100 / 97, codec-level calls
+// The reference's container WRITERS (zstdCompress ref src/lib/zstd.inc.c:254-414, lzfse_compress
+// src/lib/lzfse.inc.c:179-219, brotliCompress src/lib/brotli.inc.c:41-55, 99-128): a few header
+// bytes around the unchanged payload.  Inside zip_file_add their output is never kept (it is
+// always larger than the input, so the driver stores the entry: SURVEY F9); they are only
+// reachable through the z_stream seam (OZG_ENC_F_CODEC_ONLY).  Byte-exact.  One wavefront;
+// returns the size, or ~0u where the reference reports Z_BUF_ERROR.  The BROT header's CRC
+// field (bytes 13..16) is filled in by otz_enc_crc_kernel, which computes the CRC anyway.
+OTZ_DEV void otz_wave_copy(const u8 *src, u8 *dst, u32 n) {
+	const u32 lane = otz_tid ();
+	for (u32 c = lane; c < (n >> 4); c += OTZ_ENC_NT) {
+		otz_st16 (dst + 16ull * c, otz_ld16 (src + 16ull * c));
+	}
+	for (u32 i = (n & ~15u) + lane; i < n; i += OTZ_ENC_NT) {
+		dst[i] = src[i];
+	}
+}
+
+OTZ_DEV u32 otz_frame_entry(u32 method, const u8 *in, u32 n, u8 *out, u32 cap) {
+	const u32 lane = otz_tid ();
+	if (method == OZG_METHOD_LZFSE) {
+		if ((u64)n + 5u > cap) {
+			return ~0u;
+		}
+		if (lane < 5u) {
+			out[lane] = lane == 0 ? (u8)0x06 : (u8) (n >> (8u * (lane - 1u)));
+		}
+		otz_wave_copy (in, out + 5, n);
+		return n + 5u;
+	}
+	if (method == OZG_METHOD_BROTLI) {
+		if (cap < 17u || n > cap - 17u) {
+			return ~0u;
+		}
+		if (lane < 17u) {
+			const u8 magic[5] = { 'B', 'R', 'O', 'T', 1 };
+			out[lane] = lane < 5u ? magic[lane] : lane < 9u ? (u8) (n >> (8u * (lane - 5u))) : (u8)0; // 64-bit length; CRC later
+		}
+		otz_wave_copy (in, out + 17, n);
+		return n + 17u;
+	}
+	// method 93: magic as the reference's ENCODER writes it (its own decoder wants the other
+	// byte order), one descriptor byte, raw blocks of at most 65 535 bytes, end marker
+	const u32 nblk = (n + 65534u) / 65535u;
+	const u64 total = 5ull + n + 3ull * nblk + 3ull;
+	if (total > cap) {
+		return ~0u;
+	}
+	if (lane < 5u) {
+		const u8 hdr[5] = { 0xFD, 0x2F, 0xB5, 0x28, 0x70 };
+		out[lane] = hdr[lane];
+	}
+	for (u32 k = 0; k < nblk; k++) {
+		const u32 ip = 65535u * k, bs = n - ip < 65535u ? n - ip : 65535u;
+		u8 *b = out + 5u + (u64)k * 65538u;
+		if (lane < 3u) {
+			b[lane] = lane == 0 ? (u8)0 : (u8) (bs >> (8u * (lane - 1u)));
+		}
+		otz_wave_copy (in + ip, b + 3, bs);
+	}
+	if (lane < 3u) {
+		out[total - 3u + lane] = lane == 0 ? (u8)1 : (u8)0;
+	}
+	return (u32)total;
+}
+
 OTZ_DEV void otz_encode_entry(otz_enc_lds &L, const u8 *src, u8 *dst, const ozg_enc_entry &e, ozg_enc_result *res) {
 	const u32 lane = otz_tid ();
 	const u8 *in = src + e.src_off;
 	u8 *out = dst + e.dst_off;
 	bool stored = true;
-	const bool codec_only = e.method == OZG_METHOD_DEFLATE && (e.reserved & OZG_ENC_F_CODEC_ONLY);
+	const bool codec_only = (e.reserved & OZG_ENC_F_CODEC_ONLY) != 0 && e.method != OZG_METHOD_STORE;
 	if (((uintptr_t)out & 15u) != 0 || (e.dst_cap < e.src_size && !codec_only)) {
 		if (lane == 0) {
 			res->status = OZG_ST_INTERNAL;
@@ -408,7 +474,11 @@ OTZ_DEV void otz_encode_entry(otz_enc_lds &L, const u8 *src, u8 *dst, const ozg_
 		// codec-level call (deflate() of the z_stream seam): the stream itself is the
 		// product, there is no "not smaller -> STORE" rule at this level (ref deflate() has none)
 		u32 cs;
-		if (e.src_size > 0) {
+		if (e.method == OZG_METHOD_LZMA) {
+			cs = otz_lzma_tok_entry (in, e.src_size, out, e.dst_cap, true); // lzmaCompress itself has no "not smaller" rule
+		} else if (e.method != OZG_METHOD_DEFLATE) {
+			cs = otz_frame_entry (e.method, in, e.src_size, out, e.dst_cap);
+		} else if (e.src_size > 0) {
 			cs = otz_deflate_entry (L, in, e.src_size, out, e.dst_cap);
 		} else {
 			cs = 5; // an empty final stored block

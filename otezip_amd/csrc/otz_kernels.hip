@@ -88,7 +88,7 @@ otz_encode_kernel(const u8 *src, u8 *dst, const ozg_enc_entry *entries, ozg_enc_
 
 // CRC-32 of every input buffer of an encode batch (ref src/lib/otezip.c:1124)
 extern "C" __global__ void __launch_bounds__ (256)
-otz_enc_crc_kernel(const u8 *src, const ozg_enc_entry *entries, ozg_enc_result *results, u32 n) {
+otz_enc_crc_kernel(const u8 *src, u8 *dst, const ozg_enc_entry *entries, ozg_enc_result *results, u32 n) {
 	extern __shared__ __attribute__ ((aligned (16))) u8 otz_smem[];
 	u32 i = blockIdx.x;
 	if (i >= n) {
@@ -101,7 +101,18 @@ otz_enc_crc_kernel(const u8 *src, const ozg_enc_entry *entries, ozg_enc_result *
 	u32 m = entries[i].src_size;
 	u32 R = otz_stream_crc (L, src + entries[i].src_off, nullptr, m, false);
 	if (otz_tid () == 0) {
-		results[i].crc32 = ~(otz_gf_mul (0xFFFFFFFFu, otz_xpow_bytes (m)) ^ R);
+		const u32 crc = ~(otz_gf_mul (0xFFFFFFFFu, otz_xpow_bytes (m)) ^ R);
+		results[i].crc32 = crc;
+		// a BROT container written by the codec-level call carries this CRC (ref brotli.inc.c:49-52);
+		// the encode kernel (same stream, earlier) left the field blank
+		if (entries[i].method == OZG_METHOD_BROTLI && (entries[i].reserved & OZG_ENC_F_CODEC_ONLY) &&
+			results[i].status == OZG_ST_OK && results[i].method == OZG_METHOD_BROTLI) {
+			u8 *h = dst + entries[i].dst_off + 13;
+			h[0] = (u8)crc;
+			h[1] = (u8) (crc >> 8);
+			h[2] = (u8) (crc >> 16);
+			h[3] = (u8) (crc >> 24);
+		}
 	}
 }
 
@@ -347,8 +358,8 @@ int ozg_encode_batch_device(const void *d_src, uint64_t src_len, void *d_dst, ui
 	hipLaunchKernelGGL (otz_encode_kernel, dim3 (n), dim3 (64), sizeof (otz_enc_lds), s, (const u8 *)d_src, (u8 *)d_dst,
 		d_entries, d_results, n);
 	OZG_HIP (hipGetLastError ());
-	hipLaunchKernelGGL (otz_enc_crc_kernel, dim3 (n), dim3 (256), sizeof (otz_copy_lds), s, (const u8 *)d_src, d_entries,
-		d_results, n);
+	hipLaunchKernelGGL (otz_enc_crc_kernel, dim3 (n), dim3 (256), sizeof (otz_copy_lds), s, (const u8 *)d_src, (u8 *)d_dst,
+		d_entries, d_results, n);
 	OZG_HIP (hipGetLastError ());
 	return OZG_OK;
 }
@@ -368,7 +379,7 @@ int ozg_encode_batch_host(const void *src, uint64_t src_len, void *dst, uint64_t
 	}
 	for (uint32_t i = 0; i < n; i++) {
 		const ozg_enc_entry &e = entries[i];
-		const bool codec_only = e.method == OZG_METHOD_DEFLATE && (e.reserved & OZG_ENC_F_CODEC_ONLY);
+		const bool codec_only = (e.reserved & OZG_ENC_F_CODEC_ONLY) != 0;
 		if (e.src_off + e.src_size > src_len || (e.dst_off & 15u) || e.dst_off + e.dst_cap > dst_len || (e.dst_cap < e.src_size && !codec_only)) {
 			snprintf (g_err, sizeof (g_err), "encode entry %u: offsets outside the buffers, dst_off not a multiple of 16, or dst_cap < src_size", i);
 			return OZG_E_ARG;

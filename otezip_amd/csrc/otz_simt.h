@@ -120,6 +120,7 @@ OTZ_DEV otz_u4 otz_ld16(const void *p) {
 	__builtin_memcpy (&v, p, 16);
 	return v;
 }
+OTZ_DEV void otz_st16(void *p, otz_u4 v) { __builtin_memcpy (p, &v, 16); }
 OTZ_DEV otz_u4 otz_ld16_aligned(const void *p) { return *reinterpret_cast<const otz_u4 *> (p); }
 OTZ_DEV void otz_st16_aligned(void *p, otz_u4 v) { *reinterpret_cast<otz_u4 *> (p) = v; }
 

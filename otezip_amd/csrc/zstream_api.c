@@ -1,15 +1,21 @@
-/* zstream_api.c -- the codec seam ("Seam B") for DEFLATE: inflateInit2 / inflate /
- * inflateEnd and deflateInit2 / deflate / deflateEnd over the zlib-shaped z_stream record
- * (ref src/lib/deflate.inc.c:89-97, src/include/otezip/zlib.h:91-106, decoder
- * src/lib/deflate-dec.inc.c:547-843, encoder src/lib/deflate-enc.inc.c:262-541).
+/* zstream_api.c -- the codec seam ("Seam B"): every codec entry point the reference exports
+ * over the zlib-shaped z_stream record, 50 symbols --
+ *   inflateInit2[_] / inflate / inflateEnd, deflateInit2[_] / deflate / deflateEnd
+ *     (ref src/lib/deflate.inc.c:89-97, src/include/otezip/zlib.h:91-106; decoder
+ *     src/lib/deflate-dec.inc.c:547-843, encoder src/lib/deflate-enc.inc.c:262-541),
+ *   {zstd,lzfse,brotli,lzma}{Init,Compress,End,DecompressInit,Decompress,DecompressEnd,
+ *     CompressInit2[_],DecompressInit2[_]} (ref zstd.inc.c:135-148, lzfse.inc.c:272-372,
+ *     brotli.inc.c:82-214, lzma-enc.inc.c:92-98, lzma-dec.inc.c:84-90),
+ *   lzfse_compress / lzfse_decompress (ref lzfse.inc.c:46-47).
  *
  * The reference's own callers (otezip_extract_entry, otezip_compress_data, ref
- * src/lib/otezip.c:503-522, :819-850) hand a codec the whole input and the whole output
+ * src/lib/otezip.c:503-522, :819-1062) hand a codec the whole input and the whole output
  * buffer in one call.  That is the contract implemented here: ONE call of inflate() /
- * deflate() runs the GPU batch path (a batch of one) over next_in[0, avail_in) into
- * next_out[0, avail_out).  There is no CPU codec behind these symbols: without a GPU
- * they return Z_STREAM_ERROR.  A stream fed in pieces across several calls is not
- * supported (the second call reports Z_STREAM_END / Z_BUF_ERROR as noted below).
+ * deflate() / <codec>Compress() / <codec>Decompress() runs the GPU batch path (a batch of one)
+ * over next_in[0, avail_in) into next_out[0, avail_out).  There is no CPU codec behind these
+ * symbols: without a GPU they return Z_STREAM_ERROR.  A stream fed in pieces across several
+ * calls is not supported (a second call reports Z_STREAM_END).  The only byte work on the host is
+ * reading a private container's length field(s) so that the batch entry carries the exact size.
  *
  * Differences from the reference that a caller can observe:
  *  - total_in / next_in / avail_in: all of avail_in is reported consumed on success (the
@@ -19,7 +25,11 @@
  *  - inflate: parity rules of DESIGN.md apply (the reference's premature Z_BUF_ERROR on
  *    some valid streams is repaired; malformed input fails cleanly);
  *  - deflate: the level is ignored and the output is a VALID fixed-Huffman stream (the
- *    reference's is not); only sizes are comparable. */
+ *    reference's is not); only sizes are comparable;
+ *  - zstdCompress finishes in one call (the reference wants to be called until it stops
+ *    returning Z_OK, ref otezip.c:878-881); the bytes are the same.
+ * The container writers are byte-exact, including the reference encoder's own magic byte order
+ * for method 93 (which its decoder rejects). */
 #include <stdlib.h>
 #include <string.h>
 
@@ -29,6 +39,7 @@
 struct ozs_state {
 	int decode;
 	int finished;
+	int method;
 };
 
 static int ozs_device(void) {
@@ -36,7 +47,7 @@ static int ozs_device(void) {
 	return d ? atoi (d) : 0;
 }
 
-static int ozs_init(z_stream *strm, int decode) {
+static int ozs_init(z_stream *strm, int decode, int method) {
 	if (!strm) {
 		return Z_STREAM_ERROR;
 	}
@@ -45,6 +56,7 @@ static int ozs_init(z_stream *strm, int decode) {
 		return Z_MEM_ERROR;
 	}
 	st->decode = decode;
+	st->method = method;
 	strm->state = st;
 	strm->total_in = strm->total_out = 0;
 	strm->msg = NULL;
@@ -62,7 +74,7 @@ static int ozs_end(z_stream *strm) {
 
 int inflateInit2(z_stream *strm, int windowBits) {
 	(void)windowBits; /* raw DEFLATE, 32 KiB window, whatever is asked (ref :12-40 ignores it for raw) */
-	return ozs_init (strm, 1);
+	return ozs_init (strm, 1, OZG_METHOD_DEFLATE);
 }
 
 int inflateInit2_(z_stream *strm, int windowBits, const char *version, int stream_size) {
@@ -84,8 +96,54 @@ static void ozs_advance(z_stream *strm, uInt in_used, uInt out_made) {
 	strm->total_out += out_made;
 }
 
-int inflate(z_stream *strm, int flush) {
-	(void)flush;
+/* Payload length a private container announces, read on the host so that the batch entry can
+ * carry the exact output size (the batch path is built for zip entries, whose size is known):
+ * -1 = malformed / cannot tell (the GPU decoder then reports the error itself). */
+static long long ozs_container_len(int method, const unsigned char *p, uInt n) {
+	unsigned long long v = 0;
+	if (method == OZG_METHOD_LZFSE) { /* 0x06, LE32 length (ref lzfse.inc.c:225-257) */
+		if (n < 5) {
+			return -1;
+		}
+		return (long long)((unsigned long long)p[1] | ((unsigned long long)p[2] << 8) | ((unsigned long long)p[3] << 16) | ((unsigned long long)p[4] << 24));
+	}
+	if (method == OZG_METHOD_BROTLI) { /* LE64 at 5 (ref brotli.inc.c:57-80) */
+		if (n < 13) {
+			return -1;
+		}
+		for (int i = 7; i >= 0; i--) {
+			v = (v << 8) | p[5 + i];
+		}
+		return v > 0x7FFFFFFFull ? -1 : (long long)v;
+	}
+	if (method == OZG_METHOD_ZSTD) { /* magic, descriptor, [type|last, LE16 length, payload]* (ref zstd.inc.c:479-705) */
+		uInt at = 5;
+		if (n < 5) {
+			return -1;
+		}
+		for (;;) {
+			if (n - at < 3) {
+				return -1;
+			}
+			unsigned b0 = p[at], len = p[at + 1] | ((unsigned)p[at + 2] << 8);
+			at += 3;
+			if (((b0 >> 1) & 3u) == 1u || ((b0 >> 1) & 3u) == 3u) {
+				return -1;
+			}
+			if (n - at < len) {
+				return -1;
+			}
+			v += len;
+			at += len;
+			if (b0 & 1u) {
+				return (long long)v;
+			}
+		}
+	}
+	return -1;
+}
+
+static int ozs_decode(z_stream *strm) {
 	if (!strm || !strm->state || !strm->next_out || (!strm->next_in && strm->avail_in)) {
 		return Z_STREAM_ERROR;
 	}
@@ -100,16 +158,28 @@ int inflate(z_stream *strm, int flush) {
 		strm->msg = ozg_last_error ();
 		return Z_STREAM_ERROR;
 	}
+	uInt want = strm->avail_out;
+	/* (method 14 needs no look-ahead: its token reader stops by itself and the batch kernel
+	 * reports what it wrote even when that is not the size the entry announced) */
+	if (st->method != OZG_METHOD_DEFLATE && st->method != OZG_METHOD_LZMA) {
+		long long plen = ozs_container_len (st->method, strm->next_in, strm->avail_in);
+		if (plen >= 0) {
+			if ((unsigned long long)plen > strm->avail_out) {
+				return Z_BUF_ERROR; /* the payload does not fit the caller's buffer */
+			}
+			want = (uInt)plen;
+		}
+	}
 	ozg_entry e;
 	memset (&e, 0, sizeof (e));
 	e.comp_size = strm->avail_in;
-	e.uncomp_size = strm->avail_out;
-	e.method = OZG_METHOD_DEFLATE;
+	e.uncomp_size = want;
+	e.method = (uint16_t)st->method;
 	e.flags = OZG_EF_IGNORE_ZIPBOMB; /* the ratio guard belongs to the archive reader (ref otezip.c:454-462) */
 	ozg_result r;
 	memset (&r, 0, sizeof (r));
 	const unsigned char dummy = 0;
-	uint64_t out_len = ((uint64_t)strm->avail_out + 15u) & ~(uint64_t)15u;
+	uint64_t out_len = ((uint64_t)want + 15u) & ~(uint64_t)15u;
 	unsigned char *out = (unsigned char *)malloc (out_len ? out_len : 16);
 	if (!out) {
 		return Z_MEM_ERROR;
@@ -123,7 +193,7 @@ int inflate(z_stream *strm, int flush) {
 	int ret;
 	switch (r.status) {
 	case OZG_ST_OK:
-		/* end of the final block; a short stream leaves the rest of the buffer untouched */
+		/* end of the stream; a short DEFLATE stream leaves the rest of the buffer untouched */
 		memcpy (strm->next_out, out, r.total_out);
 		ozs_advance (strm, strm->avail_in, r.total_out);
 		st->finished = 1;
@@ -138,6 +208,18 @@ int inflate(z_stream *strm, int flush) {
 	case OZG_ST_DATA:
 		ret = Z_DATA_ERROR;
 		break;
+	case OZG_ST_SIZE:
+		if (st->method == OZG_METHOD_LZMA && r.total_out <= want) {
+			/* the token stream ended with fewer bytes than the caller's buffer holds: for a
+			 * codec-level call that is simply the end of the stream (ref lzma-dec.inc.c:297-310) */
+			memcpy (strm->next_out, out, r.total_out);
+			ozs_advance (strm, strm->avail_in, r.total_out);
+			st->finished = 1;
+			ret = Z_STREAM_END;
+			break;
+		}
+		ret = Z_BUF_ERROR;
+		break;
 	case OZG_ST_BUF:
 		ret = Z_BUF_ERROR;
 		break;
@@ -149,6 +231,11 @@ int inflate(z_stream *strm, int flush) {
 	return ret;
 }
 
+int inflate(z_stream *strm, int flush) {
+	(void)flush;
+	return ozs_decode (strm);
+}
+
 int deflateInit2(z_stream *strm, int level, int method, int windowBits, int memLevel, int strategy) {
 	(void)level; /* the reference's caller always ends up at its default level (ref otezip.c:826) */
 	(void)windowBits;
@@ -157,7 +244,7 @@ int deflateInit2(z_stream *strm, int level, int method, int windowBits, int memL
 	if (method != 8) {
 		return Z_STREAM_ERROR;
 	}
-	return ozs_init (strm, 0);
+	return ozs_init (strm, 0, OZG_METHOD_DEFLATE);
 }
 
 int deflateInit2_(z_stream *strm, int level, int method, int windowBits, int memLevel, int strategy, const char *version, int stream_size) {
@@ -170,8 +257,7 @@ int deflateEnd(z_stream *strm) {
 	return ozs_end (strm);
 }
 
-int deflate(z_stream *strm, int flush) {
-	(void)flush;
+static int ozs_encode(z_stream *strm) {
 	if (!strm || !strm->state || !strm->next_out || (!strm->next_in && strm->avail_in)) {
 		return Z_STREAM_ERROR;
 	}
@@ -190,7 +276,7 @@ int deflate(z_stream *strm, int flush) {
 	memset (&e, 0, sizeof (e));
 	e.src_size = strm->avail_in;
 	e.dst_cap = strm->avail_out;
-	e.method = OZG_METHOD_DEFLATE;
+	e.method = (uint16_t)st->method;
 	e.reserved = OZG_ENC_F_CODEC_ONLY;
 	ozg_enc_result r;
 	memset (&r, 0, sizeof (r));
@@ -218,4 +304,68 @@ int deflate(z_stream *strm, int flush) {
 	}
 	free (out);
 	return ret;
+}
+
+int deflate(z_stream *strm, int flush) {
+	(void)flush;
+	return ozs_encode (strm);
+}
+
+/* The four private container codecs behind the same calling convention (ref zstd.inc.c:135-148,
+ * :206-476, :708-752; lzfse.inc.c:272-372; brotli.inc.c:82-214; lzma-enc.inc.c:92-98, :166-340;
+ * lzma-dec.inc.c:84-90, :169-345): <c>Init / <c>Compress / <c>End, <c>DecompressInit /
+ * <c>Decompress / <c>DecompressEnd, and the Init2 / Init2_ aliases that ignore their extra
+ * arguments just as the reference's do. */
+#define OZS_CODEC(name, METHOD) \
+	int name##Init(z_stream *strm, int level) { (void)level; return ozs_init (strm, 0, METHOD); } \
+	int name##Compress(z_stream *strm, int flush) { (void)flush; return ozs_encode (strm); } \
+	int name##End(z_stream *strm) { return ozs_end (strm); } \
+	int name##DecompressInit(z_stream *strm) { return ozs_init (strm, 1, METHOD); } \
+	int name##Decompress(z_stream *strm, int flush) { (void)flush; return ozs_decode (strm); } \
+	int name##DecompressEnd(z_stream *strm) { return ozs_end (strm); } \
+	int name##CompressInit2(z_stream *strm, int level, int windowBits, int memLevel, int strategy) { \
+		(void)windowBits; (void)memLevel; (void)strategy; return name##Init (strm, level); } \
+	int name##CompressInit2_(z_stream *strm, int level, int windowBits, int memLevel, int strategy, const char *version, int stream_size) { \
+		(void)windowBits; (void)memLevel; (void)strategy; (void)version; (void)stream_size; return name##Init (strm, level); } \
+	int name##DecompressInit2(z_stream *strm, int windowBits) { (void)windowBits; return name##DecompressInit (strm); } \
+	int name##DecompressInit2_(z_stream *strm, int windowBits, const char *version, int stream_size) { \
+		(void)windowBits; (void)version; (void)stream_size; return name##DecompressInit (strm); }
+
+OZS_CODEC (zstd, OZG_METHOD_ZSTD)
+OZS_CODEC (lzfse, OZG_METHOD_LZFSE)
+OZS_CODEC (brotli, OZG_METHOD_BROTLI)
+OZS_CODEC (lzma, OZG_METHOD_LZMA)
+
+/* The reference's buffer-to-buffer lzfse pair (ref src/lib/lzfse.inc.c:46-47, :196-257):
+ * bytes written, 0 on failure. */
+size_t lzfse_compress(const void *in, size_t in_sz, void *out, size_t out_cap) {
+	z_stream s;
+	memset (&s, 0, sizeof (s));
+	if (in_sz > 0xFFFFFFFFu || out_cap > 0xFFFFFFFFu || lzfseInit (&s, 0) != Z_OK) {
+		return 0;
+	}
+	s.next_in = (const Bytef *)in;
+	s.avail_in = (uInt)in_sz;
+	s.next_out = (Bytef *)out;
+	s.avail_out = (uInt)out_cap;
+	int rc = lzfseCompress (&s, Z_FINISH);
+	size_t n = rc == Z_STREAM_END ? (size_t)s.total_out : 0;
+	lzfseEnd (&s);
+	return n;
+}
+
+size_t lzfse_decompress(const void *in, size_t in_sz, void *out, size_t out_cap) {
+	z_stream s;
+	memset (&s, 0, sizeof (s));
+	if (in_sz > 0xFFFFFFFFu || out_cap > 0xFFFFFFFFu || lzfseDecompressInit (&s) != Z_OK) {
+		return 0;
+	}
+	s.next_in = (const Bytef *)in;
+	s.avail_in = (uInt)in_sz;
+	s.next_out = (Bytef *)out;
+	s.avail_out = (uInt)out_cap;
+	int rc = lzfseDecompress (&s, Z_FINISH);
+	size_t n = rc == Z_STREAM_END ? (size_t)s.total_out : 0;
+	lzfseDecompressEnd (&s);
+	return n;
 }

@@ -133,5 +133,6 @@ OTZ_DEV otz_u4 otz_ld16(const void *p) {
 	memcpy (&v, p, 16);
 	return v;
 }
+OTZ_DEV void otz_st16(void *p, otz_u4 v) { memcpy (p, &v, 16); }
 OTZ_DEV otz_u4 otz_ld16_aligned(const void *p) { return otz_ld16 (p); }
 OTZ_DEV void otz_st16_aligned(void *p, otz_u4 v) { memcpy (p, &v, 16); }
