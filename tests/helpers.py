@@ -65,8 +65,13 @@ def emu_lib():
     global _emu
     if _emu is None:
         d = os.path.join(ROOT, "tests", "simt_emu")
-        subprocess.check_call(["make", "-s", "-C", d])
-        L = C.CDLL(os.path.join(d, "libotz_emu.so"))
+        name = "libotz_emu.so"
+        if os.environ.get("OTZ_EMU_ASAN"):   # sanitizer run: LD_PRELOAD=$(gcc -print-file-name=libasan.so) OTZ_EMU_ASAN=1 pytest ...
+            name = "libotz_emu_asan.so"
+            subprocess.check_call(["make", "-s", "-C", d, os.path.join(d, name)])
+        else:
+            subprocess.check_call(["make", "-s", "-C", d])
+        L = C.CDLL(os.path.join(d, name))
         L.emu_decode_batch.restype = C.c_int
         L.emu_decode_batch.argtypes = [C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(OzgEntry),
                                        C.POINTER(OzgResult), C.c_uint32, C.c_uint64, C.c_uint64]
