@@ -1096,36 +1096,32 @@ OTZ_DEV void otz_resolve(otz_inflate_lds &L, u32 round_base, u32 round_bytes) {
 	u32 o = 0, ri = 0, si = 0, pend = 0, pdist = 1, spins = 0;
 	bool done = false;
 	for (;;) {
-		bool progressed = false;
+		// The body is written as selects wherever a branch would only guard a few register
+		// moves: every extra branch level costs the wavefront half a dozen scalar mask
+		// instructions per iteration (cf. otz_walk).
 		// ---- 1. who needs a candidate: next granule, or next pending match of this one
-		bool poll = false;
-		u32 b = 0;
-		if (!done && pend == 0) {
-			if (pending == 0) {
-				g += OTZ_NT;
-				if (g < ngran) {
-					pending = (L.mstart[g >> (5u - OTZ_RES_GRAN_LOG)] >> (GB * (g & (32u / GB - 1u)))) & GMASK;
-					cand = pending;
-					cb = 32u;
-					progressed = true;
-				} else {
-					done = true;
-				}
-			} else {
-				if (cand == 0) {
-					cand = pending;
-				}
-				b = otz_ctz (cand);
-				cand &= cand - 1u;
-				poll = true;
-			}
+		const bool idle = !done && pend == 0;
+		const bool adv = idle && pending == 0;
+		if (adv) {
+			g += OTZ_NT;
+			const bool has = g < ngran;
+			const u32 gi = has ? g : 0u;
+			const u32 bits = (L.mstart[gi >> (5u - OTZ_RES_GRAN_LOG)] >> (GB * (gi & (32u / GB - 1u)))) & GMASK;
+			pending = has ? bits : 0u;
+			cand = pending;
+			cb = 32u;
+			done = !has;
 		}
+		bool progressed = adv && !done;
+		const bool poll = idle && !adv;
+		const u32 pool = cand ? cand : pending; // round-robin over the granule's pending matches
+		const u32 b = poll ? otz_ctz (pool | 0x80000000u) : 0u;
+		cand = poll ? pool & (pool - 1u) : cand;
 		const u32 at = GB * g + b; // round-relative start of the candidate
 		const u32 ai = OTZ_RWRAP (rb + at);
 		if (poll && b != cb) { // a retry of the same candidate keeps its descriptor
-			if (ai + 3u <= OTZ_RING) {
-				cd = otz_ld32u (&L.ring[ai]) & 0xFFFFFFu;
-			} else {
+			cd = otz_ld32u (&L.ring[ai]) & 0xFFFFFFu; // (may read past the ring's end: still inside the LDS block)
+			if (ai + 3u > OTZ_RING) {
 				cd = (u32)L.ring[ai] | ((u32)L.ring[OTZ_RWRAP (ai + 1u)] << 8) | ((u32)L.ring[OTZ_RWRAP (ai + 2u)] << 16);
 			}
 			cb = b;
@@ -1145,40 +1141,35 @@ OTZ_DEV void otz_resolve(otz_inflate_lds &L, u32 round_base, u32 round_bytes) {
 		otz_order_loads ();
 		// reads past the bytes used (and past the ring's end) land in the LDS block and are ignored
 		u64 lo = otz_ld64u (&L.ring[rs]), hi = otz_ld64u (&L.ring[rs + 8u]);
-		if (poll) {
-			bool ready;
-			if (dist >= at + span) {
-				ready = true; // source entirely before the round
-			} else if (fb - fa <= 32u) {
-				u64 need = ((((u64)1 << (fb - fa)) - 1u) << (fa & 31u));
-				u64 have = (u64)f0 | ((u64)f1 << 32);
-				ready = (have & need) == need;
-			} else {
-				ready = otz_all_final (L, fa, fb);
-				if (ready) { // the bytes read above may predate the final ones
-					lo = otz_ld64u (&L.ring[csi]);
-					hi = otz_ld64u (&L.ring[csi + 8u]);
-				}
+		const bool before = dist >= at + span; // source entirely before the round
+		const u32 flen = fb - fa;             // meaningful when !before
+		const u64 need = ((((u64)1 << (flen & 63u)) - 1u) << (fa & 31u));
+		const u64 have = (u64)f0 | ((u64)f1 << 32);
+		bool ready = poll && (before || (flen <= 32u && (have & need) == need));
+		if (poll && !before && flen > 32u) { // long source span: the general check
+			ready = otz_all_final (L, fa, fb);
+			if (ready) { // the bytes read above may predate the final ones
+				lo = otz_ld64u (&L.ring[csi]);
+				hi = otz_ld64u (&L.ring[csi + 8u]);
 			}
-			if (ready) {
-				o = at;
-				ri = ai;
-				si = csi;
-				pend = len;
-				pdist = dist;
-				pending &= ~(1u << b);
-				cb = 32u;
-			} else if ((++spins & 63u) == 0) {
-				if (otz_get_status (L) != 0) {
-					done = true;
-				} else if (spins > OTZ_SPIN_LIMIT) {
-					L.dbg[0] = 3; // waited too long for source bytes
-					L.dbg[1] = otz_tid ();
-					L.dbg[2] = round_base + at;
-					L.dbg[3] = dist | (len << 16);
-					otz_set_status (L, OZG_ST_INTERNAL);
-					done = true;
-				}
+		}
+		o = ready ? at : o;
+		ri = ready ? ai : ri;
+		si = ready ? csi : si;
+		pend = ready ? len : pend;
+		pdist = ready ? dist : pdist;
+		pending &= ~(ready ? 1u << b : 0u);
+		cb = ready ? 32u : cb;
+		if (poll && !ready && (++spins & 63u) == 0) {
+			if (otz_get_status (L) != 0) {
+				done = true;
+			} else if (spins > OTZ_SPIN_LIMIT) {
+				L.dbg[0] = 3; // waited too long for source bytes
+				L.dbg[1] = otz_tid ();
+				L.dbg[2] = round_base + at;
+				L.dbg[3] = dist | (len << 16);
+				otz_set_status (L, OZG_ST_INTERNAL);
+				done = true;
 			}
 		}
 		// ---- 3. copy one step
@@ -1229,11 +1220,11 @@ OTZ_DEV void otz_resolve(otz_inflate_lds &L, u32 round_base, u32 round_bytes) {
 			o += n;
 			ri = OTZ_RWRAP (ri + n);
 			pend -= n;
-			if (n == pdist && pdist < OTZ_RES_CHUNK) {
-				pdist += n; // a whole period written: same source, twice the reach
-			} else {
-				si = OTZ_RWRAP (si + n); // destination - source stays a multiple of the distance
-			}
+			// a whole period written: same source, twice the reach; otherwise the source
+			// slides along (destination - source stays a multiple of the distance)
+			const bool dbl = n == pdist && pdist < OTZ_RES_CHUNK;
+			si = dbl ? si : OTZ_RWRAP (si + n);
+			pdist += dbl ? n : 0u;
 		}
 		u64 alive = otz_ballot (!done);
 		u64 moved = otz_ballot (progressed);
