@@ -1,10 +1,12 @@
 // otz_kernels.hip -- gfx950 kernels and the ozg_* C ABI (include/otezip_gpu.h).
 //
-// Two kernels, one workgroup per archive entry (256 lanes = 4 wavefronts):
-//   otz_inflate_kernel  DEFLATE entries; 79 KB of LDS per workgroup -> two
-//                       resident workgroups per CU (160 KB LDS), 512 entries in
-//                       flight on the chip
-//   otz_copy_kernel     STORE and the private raw framings; 11 KB of LDS
+// Decode kernels, one workgroup per archive entry:
+//   otz_inflate_kernel  DEFLATE entries; 512 lanes (8 wavefronts), 77 KB of LDS per
+//                       workgroup -> two resident workgroups per CU (160 KB LDS,
+//                       <= 128 VGPRs), 512 entries in flight on the chip
+//   otz_copy_kernel     STORE and the private raw framings; 256 lanes, 11 KB of LDS
+// Encode kernels, one buffer each: otz_encode_kernel (one wavefront: DEFLATE, the private
+// framings' writers, STORE) and otz_enc_crc_kernel (CRC-32 of the input).
 // Entries are independent, so the blockIdx -> entry map needs no XCD-aware
 // remap: there is no operand shared between workgroups to keep in one L2.
 //
