@@ -1022,12 +1022,8 @@ OTZ_DEV void otz_place(otz_inflate_lds &L, const otz_dec &D, bool active, u32 st
 		stopped = kind >= OTZ_K_EOB || too_far;
 		const u32 w = rel >> 5;
 		if (w != curw) {
-			if (finm) {
-				otz_lds_or (&L.fin[curw], finm);
-			}
-			if (stm) {
-				otz_lds_or (&L.mstart[curw], stm);
-			}
+			otz_lds_or (&L.fin[curw], finm); // (an OR of zero is cheaper than a branch around it)
+			otz_lds_or (&L.mstart[curw], stm);
 			curw = w;
 			finm = stm = 0;
 		}
