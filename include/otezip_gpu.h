@@ -171,7 +171,8 @@ int ozg_stream_sync(void *stream);
 void ozg_debug_set_profile_buffer(void *d_buf);
 
 /* Names of the kernels a profiler will show, for tooling. */
-const char *ozg_kernel_name_inflate(void);
+const char *ozg_kernel_name_inflate(void); /* second half of the DEFLATE decode (index -> bytes) */
+const char *ozg_kernel_name_index(void);   /* first half (token chain -> index) */
 const char *ozg_kernel_name_copy(void);
 
 #ifdef __cplusplus

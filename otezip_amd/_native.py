@@ -79,6 +79,7 @@ ABI = {
     "ozg_stream_sync": (C.c_int, [_VP]),
     "ozg_debug_set_profile_buffer": (None, [_VP]),
     "ozg_kernel_name_inflate": (C.c_char_p, []),
+    "ozg_kernel_name_index": (C.c_char_p, []),
     "ozg_kernel_name_copy": (C.c_char_p, []),
 }
 

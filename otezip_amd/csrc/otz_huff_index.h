@@ -1,0 +1,777 @@
+// otz_huff_index.h -- first half of the DEFLATE decode: ONE WAVEFRONT finds the token chain
+// of one entry and writes the index of otz_index.h.  (ref: the symbol loop of inflate(),
+// src/lib/deflate-dec.inc.c:610-817, block headers :122-253, stored blocks :269-319.)
+//
+// A Huffman stream can only be cut where a token starts, and that is only known once
+// everything before it has been decoded.  The wavefront breaks the chain the way the
+// workgroup kernel of otz_inflate.h does, but with segments long enough that the extra
+// work stays small and with nothing but wave-level operations:
+//
+//   * a round covers 64 x OTZ_K1_S bits of input; lane l owns the segment
+//     [s_l, s_l + OTZ_K1_S).  The bytes of every lane (plus a warm-up stretch before and a
+//     token's reach behind its segment) sit in a private LDS slot with an odd dword
+//     stride: one unaligned 8-byte LDS read per token fetches its bits, free of bank
+//     conflicts although all lanes sit at the same offset of their segments;
+//   * walk A: every lane but lane 0 starts OTZ_K1_WARM bits BEFORE its segment at a
+//     guessed position.  A prefix code decoded from a wrong position falls into step with
+//     the real chain after a few tokens, so by s_l the lane is usually on it.  From s_l on
+//     the lane notes a checkpoint (bit position, output bytes so far) every OTZ_IX_G
+//     tokens, in a row of its region's temp area;
+//   * fixpoint: lane l's true start is where lane l-1 really ended (one v_mov_dpp).  If
+//     that is the first token walk A saw in the segment, the lane is confirmed; otherwise
+//     walk B re-decodes from the true start until it lands on one of walk A's checkpoints
+//     (or the segment ends).  A lane whose end moved makes its right neighbour repeat;
+//     with 512-bit segments that almost never cascades;
+//   * the first lane whose path ends the block, breaks, or runs out of input (or that
+//     exceeds its token budget) closes the round; the lanes before it are accepted: prefix
+//     sums give every item its output position and its slot in the block's item list.
+//
+// Nothing here waits on another wavefront: the kernel is launched with one 64-lane
+// workgroup per entry and the chip keeps ~13 of them per CU in flight.
+#pragma once
+
+#include "otz_inflate.h"
+#include "otz_index.h"
+
+#define OTZ_K1_S 512u     // segment bits per lane per round
+#define OTZ_K1_WARM 128u  // head start of walk A (bits)
+#define OTZ_K1_SLOT 92u   // slot bytes per lane: WARM/8 before + S/8 + 12 behind; 23 dwords (odd: no bank conflicts)
+#define OTZ_K1_NCAP (OTZ_K1_ROWS * OTZ_IX_G) // tokens a walk may take per round
+#define OTZ_K1_HDR_WORDS 264u // staged bytes for a block header: 17 + 57 + 318 x 14 bits < 1056 bytes
+
+static_assert (OTZ_K1_S % 8u == 0 && OTZ_K1_WARM % 8u == 0, "byte-granular slots");
+static_assert (OTZ_K1_SLOT % 4u == 0 && (OTZ_K1_SLOT / 4u) % 2u == 1u, "odd dword stride");
+static_assert (OTZ_K1_SLOT >= OTZ_K1_WARM / 8u + OTZ_K1_S / 8u + 9u, "a token starting on the segment's last bit must fit");
+static_assert ((OTZ_IX_G & (OTZ_IX_G - 1u)) == 0, "power of two");
+
+#define OTZ_K1_NONE 0xFFFFFFFFu
+#define OTZ_X_CAP 2u // exit kind: token budget of the round used up (not an error; the block goes on)
+
+struct otz_k1_lds {
+	u32 lit_lut[OTZ_LIT_LUT];
+	u32 dist_lut[OTZ_DIST_LUT];
+	union {
+		u8 slots[64u * OTZ_K1_SLOT + 16u];
+		struct { // block prologue only
+			u32 hdr_w[OTZ_K1_HDR_WORDS + 4u];
+			u32 cl_lut[128];
+			u8 ll[OTZ_IX_LENS];
+			u16 rank[OTZ_IX_LENS];
+		} h;
+	};
+};
+
+// ------------------------------------------------------------------ wave helpers
+
+OTZ_DEV u32 otz_wave_scan_incl(u32 v) {
+	const u32 lane = otz_lane ();
+#pragma unroll
+	for (u32 d = 1; d < 64; d <<= 1) {
+		u32 o = otz_shfl_up (v, d);
+		if (lane >= d) {
+			v += o;
+		}
+	}
+	return v;
+}
+
+// 16 bytes of the entry at byte offset off (may be negative or run past the end: zeros there)
+OTZ_DEV otz_u4 otz_k1_ld16(const u8 *in, u32 n_in, int64_t off) {
+	if (off >= 0 && off + 16 <= (int64_t)n_in) {
+		return otz_ld16 (in + off);
+	}
+	u32 w[4] = { 0, 0, 0, 0 };
+	if (off + 16 > 0 && off < (int64_t)n_in) {
+		for (u32 k = 0; k < 16; k++) {
+			int64_t q = off + k;
+			if (q >= 0 && q < (int64_t)n_in) {
+				w[k >> 2] |= (u32)in[q] << (8u * (k & 3u));
+			}
+		}
+	}
+	otz_u4 v;
+	v.x = w[0];
+	v.y = w[1];
+	v.z = w[2];
+	v.w = w[3];
+	return v;
+}
+
+// ------------------------------------------------------------------ block header
+
+OTZ_DEV u32 otz_k1_hbits(const otz_k1_lds &L, u32 p) { // 32 staged bits from bit p
+	const u32 w = p >> 5;
+	return otz_alignbit (L.h.hdr_w[w + 1u], L.h.hdr_w[w], p & 31u);
+}
+
+// BFINAL/BTYPE and HLIT/HDIST/HCLEN of a dynamic block plus the 7-bit table of the
+// code-length code (ref deflate-dec.inc.c:613-627, :122-156); same construction as
+// otz_parse_header_par, one wavefront.  *cl_ok = 0 for an over-subscribed code-length code.
+OTZ_DEV otz_hdr otz_k1_parse_header(otz_k1_lds &L, u32 p, u64 avail, u32 *cl_ok) {
+	otz_hdr H;
+	H.st = 0;
+	H.bfinal = H.btype = H.hlit = H.hdist = 0;
+	H.bits = 3;
+	*cl_ok = 1;
+	const u32 lo = otz_k1_hbits (L, p);
+	if (avail < 3u) {
+		H.st = OZG_ST_BUF;
+		return H;
+	}
+	H.bfinal = lo & 1u;
+	H.btype = (lo >> 1) & 3u;
+	if (H.btype == 3u) {
+		H.st = OZG_ST_DATA;
+		return H;
+	}
+	if (H.btype != 2u) {
+		return H;
+	}
+	H.hlit = ((lo >> 3) & 31u) + 257u;
+	H.hdist = ((lo >> 8) & 31u) + 1u;
+	const u32 hclen = ((lo >> 13) & 15u) + 4u;
+	H.bits = 17u + 3u * hclen;
+	if (avail < H.bits || H.hlit + H.hdist > 318u) { // ref LL_LENGTHS_MAX (:165-168)
+		H.st = OZG_ST_DATA;
+		return H;
+	}
+	const u32 lane = otz_lane ();
+	L.h.cl_lut[lane] = 0;
+	L.h.cl_lut[lane + 64u] = 0;
+	otz_wave_sync ();
+	const u64 inv_lo = 3ull | (17ull << 5) | (15ull << 10) | (13ull << 15) | (11ull << 20) | (9ull << 25) | (7ull << 30) | (5ull << 35) |
+		(4ull << 40) | (6ull << 45) | (8ull << 50) | (10ull << 55);
+	const u64 inv_hi = 12ull | (14ull << 5) | (16ull << 10) | (18ull << 15) | (0ull << 20) | (1ull << 25) | (2ull << 30);
+	u32 l = 0;
+	if (lane < 19u) {
+		u32 slot = (u32) ((lane < 12u ? inv_lo >> (5u * lane) : inv_hi >> (5u * (lane - 12u))) & 31u);
+		if (slot < hclen) {
+			l = otz_k1_hbits (L, p + 17u + 3u * slot) & 7u;
+		}
+	}
+	const u64 below = ((u64)1 << lane) - 1u;
+	u32 code = 0, kraft = 0, my_first = 0, rank = 0;
+	for (u32 k = 1; k <= 7u; k++) {
+		u64 m = otz_ballot (l == k);
+		u32 cnt = otz_popc64 (m);
+		if (l == k) {
+			my_first = code;
+			rank = otz_popc64 (m & below);
+		}
+		code = (code + cnt) << 1;
+		kraft += cnt << (7u - k);
+	}
+	if (l) {
+		u32 rr = otz_brev (my_first + rank) >> (32u - l);
+		for (u32 idx = rr; idx < 128u; idx += 1u << l) {
+			L.h.cl_lut[idx] = (lane << 8) | l;
+		}
+	}
+	*cl_ok = kraft <= 128u ? 1u : 0u;
+	otz_wave_sync ();
+	return H;
+}
+
+// The hlit + hdist run-length coded code lengths (ref deflate-dec.inc.c:164-253), 64 bit
+// positions per step: every lane decodes the code-length token that WOULD start at its
+// bit, a scalar walk (v_readlane) follows the real chain through the 64 positions, a
+// prefix sum places the tokens.  Tokens write only the START of their run ("this length
+// from here on"); a fill-forward pass expands the runs, which also resolves symbol 16
+// ("repeat the previous length") without a serial pass.
+// Returns 0 and the bits consumed, or OZG_ST_DATA.
+OTZ_DEV int otz_k1_parse_lengths(otz_k1_lds &L, u32 p, u64 avail, u32 n, u32 *bits_used) {
+	const u32 lane = otz_lane ();
+	for (u32 i = lane; i < OTZ_IX_LENS; i += 64u) {
+		L.h.ll[i] = 0;
+	}
+	otz_wave_sync ();
+	u32 idx = 0, pos = 0;
+	while (idx < n) {
+		const u32 at = pos + lane;
+		const u32 bits = otz_k1_hbits (L, p + at);
+		const u32 e = L.h.cl_lut[bits & 127u];
+		const u32 l = e & 15u, sym = e >> 8;
+		const u32 xb = sym < 16u ? 0u : sym == 16u ? 2u : sym == 17u ? 3u : 7u;
+		const u32 cnt = sym < 16u ? 1u : ((bits >> l) & ((1u << xb) - 1u)) + (sym == 18u ? 11u : 3u);
+		u32 nb = l + xb;
+		if (l == 0 || (u64)at + nb > avail) {
+			nb = 0; // no token can start here: unused code or out of input
+		}
+		u64 starts = 0;
+		u32 cur = 0, got = idx;
+		bool fail = false;
+		while (cur < 64u && got < n) {
+			const u32 step = otz_readlane (nb, cur);
+			const u32 c = otz_readlane (cnt, cur);
+			if (step == 0) {
+				fail = true;
+				break;
+			}
+			starts |= (u64)1 << cur;
+			got += c;
+			cur += step;
+		}
+		if (fail || got > n) { // bad code, out of input, or a run past hlit + hdist
+			return OZG_ST_DATA;
+		}
+		const bool is_start = ((starts >> lane) & 1u) != 0;
+		const u32 mine = is_start ? cnt : 0u;
+		const u32 my_idx = idx + otz_wave_scan_incl (mine) - mine;
+		const bool rep0 = is_start && sym == 16u && my_idx == 0; // nothing to repeat
+		if (otz_ballot (rep0) != 0) {
+			return OZG_ST_DATA;
+		}
+		if (is_start && sym != 16u) {
+			L.h.ll[my_idx] = (u8) (0x80u | (sym < 16u ? sym : 0u));
+		}
+		idx = got;
+		pos += cur;
+	}
+	otz_wave_sync ();
+	u32 carry = 0xFFu;
+	for (u32 base = 0; base < n; base += 64u) {
+		const u32 i = base + lane;
+		const u32 v = i < n ? L.h.ll[i] : 0u;
+		const u64 m = otz_ballot ((v & 0x80u) != 0);
+		const u64 mm = m & (~(u64)0 >> (63u - lane));
+		const u32 srcl = mm ? 63u - otz_clz64 (mm) : 0u;
+		u32 val = otz_shfl (v & 0x1Fu, srcl);
+		val = mm ? val : carry;
+		otz_wave_sync ();
+		if (i < n) {
+			L.h.ll[i] = (u8)val;
+		}
+		carry = otz_readlane (val, 63u);
+	}
+	otz_wave_sync ();
+	*bits_used = pos;
+	return 0;
+}
+
+// Both two-level decode tables from L.h.ll[0..hlit+hdist): the construction of
+// otz_build_tables (canonical code = first[len] + rank among the symbols of that length,
+// rank from ballots; root slots written by the symbol, sub-tables placed by a prefix sum
+// over the root slots), with one wavefront looping over chunks of 64 symbols / slots.
+// Returns false for an over-subscribed set or sub-tables that do not fit.
+OTZ_DEV bool otz_k1_build_tables(otz_k1_lds &L, u32 hlit, u32 hdist) {
+	constexpr u32 LRSZ = 1u << OTZ_LIT_ROOT, DRSZ = 1u << OTZ_DIST_ROOT;
+	const u32 lane = otz_lane ();
+	const u64 below = ((u64)1 << lane) - 1u;
+	for (u32 i = lane; i < OTZ_LIT_LUT; i += 64u) {
+		L.lit_lut[i] = OTZ_LUT_NONE;
+	}
+	for (u32 i = lane; i < OTZ_DIST_LUT; i += 64u) {
+		L.dist_lut[i] = OTZ_LUT_NONE;
+	}
+	bool ok = true;
+	for (u32 tbl = 0; tbl < 2u; tbl++) {
+		const u32 nsym = tbl ? hdist : hlit, at0 = tbl ? hlit : 0u;
+		const u32 root = tbl ? OTZ_DIST_ROOT : OTZ_LIT_ROOT, rsz = tbl ? DRSZ : LRSZ, cap = tbl ? OTZ_DIST_LUT : OTZ_LIT_LUT;
+		u32 *const lut = tbl ? L.dist_lut : L.lit_lut;
+		// lane k (1..15) counts the symbols of length k; every symbol notes its rank
+		u32 cnt = 0;
+		for (u32 base = 0; base < nsym; base += 64u) {
+			const u32 sym = base + lane;
+			const u32 l = sym < nsym ? L.h.ll[at0 + sym] : 0u;
+			const u32 before = otz_shfl (cnt, l);
+			u32 rank = 0;
+			for (u32 k = 1; k <= 15u; k++) {
+				const u64 m = otz_ballot (l == k);
+				if (l == k) {
+					rank = otz_popc64 (m & below);
+				}
+				if (lane == k) {
+					cnt += otz_popc64 (m);
+				}
+			}
+			if (sym < nsym) {
+				L.h.rank[at0 + sym] = (u16) (before + rank);
+			}
+		}
+		// lane l: first code of length l = sum over j < l of count[j] << (l - j)
+		u32 first = 0;
+		for (u32 j = 1; j < 15u; j++) {
+			const u32 cj = otz_readlane (cnt, j);
+			if (lane > j && lane < 16u) {
+				first += cj << (lane - j);
+			}
+		}
+		// over-subscribed (ref: "left < 0") exactly when first[15] + count[15] > 2^15
+		ok = ok && otz_readlane (first + cnt, 15u) <= (1u << 15);
+		otz_wave_sync ();
+		// the symbols write their root slots, or claim a sub-table under their root slot
+		for (u32 base = 0; base < nsym; base += 64u) {
+			const u32 sym = base + lane;
+			const u32 l = sym < nsym ? L.h.ll[at0 + sym] : 0u;
+			const u32 f = otz_shfl (first, l);
+			if (l) {
+				const u32 rr = otz_brev (f + L.h.rank[at0 + sym]) >> (32u - l);
+				if (l <= root) {
+					const u32 e = tbl ? otz_mk_dist_entry (sym, l) : otz_mk_lit_entry (sym, l);
+					for (u32 idx = rr; idx < rsz; idx += 1u << l) {
+						lut[idx] = e;
+					}
+				} else {
+					otz_lds_max (&lut[rr & (rsz - 1u)], (l - root) << 8);
+				}
+			}
+		}
+		otz_wave_sync ();
+		// sub-table placement: running sum over the root slots
+		u32 total = 0;
+		for (u32 base = 0; base < rsz; base += 64u) {
+			const u32 slot = base + lane;
+			const u32 e = lut[slot];
+			const u32 sz = e && (e & 0xFFu) == 0 ? 1u << (e >> 8) : 0u; // claimed: (widest code - root) << 8
+			const u32 incl = otz_wave_scan_incl (sz);
+			const u32 tot = otz_readlane (incl, 63u);
+			if (sz && total + tot <= cap - rsz) {
+				lut[slot] = OTZ_LUT_LINK | ((rsz + total + incl - sz) << 16) | ((e >> 8) << 8) | OTZ_LUT_NONE;
+			}
+			total += tot;
+		}
+		if (total > cap - rsz) {
+			ok = false;
+		}
+		otz_wave_sync ();
+		if (ok) {
+			for (u32 base = 0; base < nsym; base += 64u) {
+				const u32 sym = base + lane;
+				const u32 l = sym < nsym ? L.h.ll[at0 + sym] : 0u;
+				const u32 f = otz_shfl (first, l);
+				if (l > root) {
+					const u32 rr = otz_brev (f + L.h.rank[at0 + sym]) >> (32u - l);
+					const u32 e = tbl ? otz_mk_dist_entry (sym, l) : otz_mk_lit_entry (sym, l);
+					const u32 link = lut[rr & (rsz - 1u)];
+					const u32 sb = (link >> 8) & 15u, sbase = (link >> 16) & 0x7FFFu;
+					for (u32 idx = rr >> root; idx < (1u << sb); idx += 1u << (l - root)) {
+						lut[sbase + idx] = e;
+					}
+				}
+			}
+		}
+		otz_wave_sync ();
+	}
+	return ok;
+}
+
+// ------------------------------------------------------------------ the walks
+
+struct otz_k1_path {
+	u32 exit;   // OTZ_X_MAKE (kind, slot-relative bit position): next token start, or the position after an EOB code
+	u32 n;      // tokens taken (each produced output)
+	u32 bytes;  // their output bytes
+	u32 nck;    // checkpoints written
+	u32 first;  // walk A: first token start at or behind the segment start (OTZ_K1_NONE: none); walk B: unused
+	u32 tstart; // start of the token examined last (the EOB code when the walk ended on one)
+	u32 merge;  // walk B: index of walk A's checkpoint it landed on, or OTZ_K1_NONE
+};
+
+// One token at slot-relative bit u: one unaligned 8-byte LDS read covers its 48 bits at most.
+OTZ_DEV otz_tok otz_k1_decode(const otz_k1_lds &L, const u8 *slot, u32 u) {
+	const u64 w = otz_ld64u (slot + (u >> 3)) >> (u & 7u);
+	return otz_decode_bits (L, (u32)w, (u32) (w >> 32));
+}
+
+// Walk A (SPEC): from `start`; tokens before s are warm-up (neither counted nor noted).
+// Walk B (!SPEC): from the lane's true start; every token counts; stops on a checkpoint
+// position of walk A (ck_first = its first, rowsA/nckA the rest).
+// Straight-line loop body, one loop condition (cf. otz_walk in otz_inflate.h).
+template <bool SPEC>
+OTZ_DEV otz_k1_path otz_k1_walk(const otz_k1_lds &L, const u8 *slot, bool run, u32 start, u32 s, u32 e, u32 limit,
+	otz_ix_item *rows, const otz_ix_item *rowsA, u32 ck_first, u32 nckA) {
+	const u32 lane = otz_lane ();
+	otz_k1_path P;
+	u32 u = start, n = 0, bytes = 0, nck = 0, first = OTZ_K1_NONE, tstart = start;
+	u32 kind = OTZ_K_LIT, tend = start;
+	bool term = false, merged = false;
+	u32 c = 0, cpos = ck_first; // walk B: next checkpoint of walk A at or behind u
+	bool active = run;
+	while (otz_ballot (active) != 0) {
+		if (active) {
+			if (!SPEC) {
+				while (cpos < u) {
+					c++;
+					cpos = c < nckA ? rowsA[c * 64u + lane].bit : OTZ_K1_NONE;
+				}
+				merged = cpos == u;
+			}
+			if (!merged) {
+				const bool counted = !SPEC || u >= s;
+				if (counted && first == OTZ_K1_NONE) {
+					first = u;
+				}
+				if (counted && (n & (OTZ_IX_G - 1u)) == 0) {
+					otz_ix_item ck;
+					ck.bit = u;
+					ck.out = bytes;
+					rows[nck * 64u + lane] = ck;
+					nck++;
+				}
+				const otz_tok t = otz_k1_decode (L, slot, u);
+				kind = t.kind;
+				tstart = u;
+				tend = u + t.nbits;
+				term = kind >= OTZ_K_EOB || tend > limit;
+				if (!term) {
+					u = tend;
+					n += counted ? 1u : 0u;
+					bytes += counted ? (kind == OTZ_K_LIT ? 1u : t.val) : 0u;
+				}
+			}
+			active = !merged && !term && u < e && n < OTZ_K1_NCAP;
+		}
+	}
+	u32 xk = OTZ_X_NORMAL, xp = u;
+	if (term) {
+		if (kind == OTZ_K_BAD) {
+			xk = u >= limit ? OTZ_X_TRUNC : OTZ_X_INVALID;
+		} else if (tend > limit) {
+			xk = OTZ_X_TRUNC;
+		} else {
+			xk = OTZ_X_EOB;
+			xp = tend;
+		}
+	} else if (!merged && u < e) {
+		xk = OTZ_X_CAP; // n == OTZ_K1_NCAP
+	}
+	P.exit = OTZ_X_MAKE (xk, xp);
+	P.n = n;
+	P.bytes = bytes;
+	P.nck = nck;
+	P.first = first;
+	P.tstart = tstart;
+	P.merge = merged ? c : OTZ_K1_NONE;
+	return P;
+}
+
+// ------------------------------------------------------------------ the entry
+
+#define OTZ_K1_ST_NEED_OUT (-100) // internal: OZG_ST_NEED_OUT is 0
+
+// All 64 lanes.  in/n_in: the compressed payload; out_cap: uncomp_size; out_aligned: the
+// entry's output address is 16-byte aligned; region/region_bytes: the entry's arena region
+// (region_bytes = 0: none could be carved).  head: the entry's index head.
+// Returns true when the index did not fit (head->status = OTZ_IX_OVERFLOW).
+OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap, bool out_aligned, u8 *region, u32 region_bytes, otz_ix_head *head) {
+	const u32 lane = otz_lane ();
+	const u64 total_bits = (u64)n_in * 8u;
+	u64 abs_bit = 0;
+	u32 opos = 0;
+	int status = 0;
+	u32 flags = 0, n_blocks = 0;
+	u32 rec = 32u; // region offset of the next block record
+	u32 last_btype = 0;
+	u64 eob_abs = 0;
+	bool last_block = false, ended = false;
+	u32 prev_next_at = 0; // region offset of the previous block's `next` field (0: none)
+
+	if (!out_aligned) {
+		status = OZG_ST_INTERNAL;
+	} else if (n_in == 0) {
+		// ref: the loop at :610 never runs; Z_OK when there is no output space, else Z_BUF_ERROR
+		status = out_cap == 0 ? OTZ_K1_ST_NEED_OUT : OZG_ST_BUF;
+	} else if (region_bytes < OTZ_K1_TEMP_BYTES + 1024u) {
+		status = OTZ_IX_OVERFLOW;
+	}
+	const u32 rec_limit = region_bytes >= OTZ_K1_TEMP_BYTES ? region_bytes - OTZ_K1_TEMP_BYTES : 0u;
+	otz_ix_item *const rowsA = reinterpret_cast<otz_ix_item *> (region + rec_limit);
+	otz_ix_item *const rowsB = rowsA + OTZ_K1_ROWS * 64u;
+
+	while (status == 0 && !ended) {
+		// ---- block header: stage the bytes behind the current position
+		const u32 hb = (u32) (abs_bit >> 3);
+		{
+			const otz_u4 v = otz_k1_ld16 (in, n_in, (int64_t)hb + 16 * (int64_t)lane);
+			otz_wave_sync (); // the slots of the previous round are dead from here
+			u32 *d = &L.h.hdr_w[4u * lane];
+			d[0] = v.x;
+			d[1] = v.y;
+			d[2] = v.z;
+			d[3] = v.w;
+			if (lane < 2u) {
+				const otz_u4 t = otz_k1_ld16 (in, n_in, (int64_t)hb + 1024 + 16 * (int64_t)lane);
+				u32 *d2 = &L.h.hdr_w[256u + 4u * lane];
+				d2[0] = t.x;
+				d2[1] = t.y;
+				d2[2] = t.z;
+				d2[3] = t.w;
+			}
+			otz_wave_sync ();
+		}
+		const u32 hp = (u32) (abs_bit & 7u);
+		u32 cl_ok = 1;
+		const otz_hdr H = otz_k1_parse_header (L, hp, total_bits - abs_bit, &cl_ok);
+		if (H.st != 0 || (H.btype == 2u && !cl_ok)) {
+			status = H.st != 0 ? H.st : OZG_ST_DATA;
+			break;
+		}
+		last_block = H.bfinal != 0;
+		last_btype = H.btype;
+		abs_bit += H.bits;
+		if (rec + 32u > rec_limit) {
+			status = OTZ_IX_OVERFLOW;
+			break;
+		}
+		otz_ix_block *const blk = reinterpret_cast<otz_ix_block *> (region + rec);
+		if (H.btype == 0) {
+			// ---- stored block (ref read_uncompressed_block :269-319)
+			abs_bit = (abs_bit + 7u) & ~(u64)7u;
+			u32 b = (u32) (abs_bit >> 3);
+			if (b > n_in || n_in - b < 4u) {
+				status = OZG_ST_DATA;
+				break;
+			}
+			const u32 len = (u32)in[b] | ((u32)in[b + 1] << 8);
+			const u32 nlen = (u32)in[b + 2] | ((u32)in[b + 3] << 8);
+			b += 4;
+			if (len != ((~nlen) & 0xFFFFu) || n_in - b < len) {
+				status = OZG_ST_DATA;
+				break;
+			}
+			if (out_cap - opos < len) {
+				status = OZG_ST_BUF; // ref :299-301
+				break;
+			}
+			if (lane == 0) {
+				blk->kind = OTZ_IX_KIND_STORED;
+				blk->n_items = 0;
+				blk->bit_lo = b;
+				blk->bit_hi = 0;
+				blk->out_base = opos;
+				blk->out_len = len;
+				blk->hlit_hdist = 0;
+				blk->next = 0;
+				if (prev_next_at) {
+					*reinterpret_cast<u32 *> (region + prev_next_at) = rec;
+				}
+			}
+			prev_next_at = rec + 28u;
+			rec += 32u;
+			n_blocks++;
+			opos += len;
+			abs_bit = ((u64)b + len) * 8u;
+			ended = last_block;
+			continue;
+		}
+		// ---- Huffman block: code lengths, tables
+		u32 hlit = 288, hdist = 32;
+		if (H.btype == 1) {
+			for (u32 i = lane; i < OTZ_IX_LENS; i += 64u) {
+				L.h.ll[i] = (u8) (i <= 143u ? 8 : i <= 255u ? 9 : i <= 279u ? 7 : i <= 287u ? 8 : 5);
+			}
+			otz_wave_sync ();
+		} else {
+			hlit = H.hlit;
+			hdist = H.hdist;
+			u32 used = 0;
+			const int st = otz_k1_parse_lengths (L, hp + H.bits, total_bits - abs_bit, hlit + hdist, &used);
+			if (st != 0) {
+				status = st;
+				break;
+			}
+			abs_bit += used;
+		}
+		if (rec + OTZ_IX_ITEMS_OFF + 8u > rec_limit) {
+			status = OTZ_IX_OVERFLOW;
+			break;
+		}
+		for (u32 i = lane; i < OTZ_IX_LENS / 4u; i += 64u) { // the apply kernel rebuilds the tables from these
+			u32 w = 0;
+			for (u32 k = 0; k < 4u; k++) {
+				const u32 j = 4u * i + k;
+				w |= (j < hlit + hdist ? (u32)L.h.ll[j] : 0u) << (8u * k);
+			}
+			reinterpret_cast<u32 *> (region + rec + 32u)[i] = w;
+		}
+		if (!otz_k1_build_tables (L, hlit, hdist)) {
+			status = OZG_ST_DATA;
+			break;
+		}
+		otz_ix_item *const items = reinterpret_cast<otz_ix_item *> (region + rec + OTZ_IX_ITEMS_OFF);
+		const u32 items_cap = (rec_limit - rec - OTZ_IX_ITEMS_OFF) / 8u; // >= 1
+		const u64 block_bit = abs_bit;
+		const u32 block_out = opos;
+		u32 n_items = 0;
+		u32 end_bit = 0; // block-relative position that closes the item list
+		bool block_done = false;
+
+		// ---- rounds
+		while (!block_done && status == 0) {
+			const u32 rb = (u32) (abs_bit >> 3), phi = (u32) (abs_bit & 7u);
+			const int64_t slot0 = (int64_t)rb + 64 * (int64_t)lane - (int64_t) (OTZ_K1_WARM / 8u); // entry byte of the slot's byte 0
+			u8 *const slot = &L.slots[lane * OTZ_K1_SLOT];
+			otz_wave_sync (); // prologue scratch / previous round's slots are dead
+			for (u32 k = 0; k < OTZ_K1_SLOT / 16u; k++) {
+				const otz_u4 v = otz_k1_ld16 (in, n_in, slot0 + 16 * (int64_t)k);
+				u32 *d = reinterpret_cast<u32 *> (slot + 16u * k);
+				d[0] = v.x;
+				d[1] = v.y;
+				d[2] = v.z;
+				d[3] = v.w;
+			}
+			{
+				const otz_u4 v = otz_k1_ld16 (in, n_in, slot0 + 16 * (int64_t) (OTZ_K1_SLOT / 16u));
+				u32 *d = reinterpret_cast<u32 *> (slot + 16u * (OTZ_K1_SLOT / 16u));
+				d[0] = v.x;
+				d[1] = v.y;
+				d[2] = v.z;
+			}
+			otz_wave_sync ();
+			// slot-relative bit coordinates: the lane's segment is [s, e)
+			const u32 s = OTZ_K1_WARM + phi, e = s + OTZ_K1_S;
+			const int64_t lb = (int64_t)total_bits - 8 * slot0; // the input ends at this slot-relative bit
+			const u32 limit = lb <= 0 ? 0u : lb > 0xFFFFFF ? 0xFFFFFFu : (u32)lb;
+			// ---- walk A
+			const otz_k1_path A = otz_k1_walk<true> (L, slot, true, lane ? s - OTZ_K1_WARM : s, s, e, limit, rowsA, rowsA, 0, 0);
+			// ---- fixpoint over the true starts
+			u32 t = lane == 0 ? s : OTZ_K1_NONE;
+			u32 exit_cur = A.exit;
+			bool onA = true;     // the true path is walk A's from checkpoint cm on
+			u32 cm = 0;          // (lane 0: walk A is the true path)
+			otz_k1_path B;
+			B.n = B.bytes = B.nck = 0;
+			B.exit = 0;
+			B.tstart = 0;
+			B.merge = OTZ_K1_NONE;
+			B.first = 0;
+			for (u32 it = 0; it < 64u; it++) {
+				const u32 prev = otz_shfl_up (exit_cur, 1);
+				// the left neighbour's exit is slot-relative to ITS slot: one segment further left
+				const u32 nt = lane && OTZ_X_KIND (prev) == OTZ_X_NORMAL ? OTZ_X_POS (prev) - OTZ_K1_S : OTZ_K1_NONE;
+				const bool moved = lane != 0 && nt != t && nt != OTZ_K1_NONE;
+				t = lane ? nt : t;
+				const bool rewalk = moved && nt != A.first;
+				const u32 old_exit = exit_cur;
+				if (otz_ballot (rewalk) != 0) {
+					const otz_k1_path W = otz_k1_walk<false> (L, slot, rewalk, nt, s, e, limit, rowsB, rowsA, A.first, A.nck);
+					if (rewalk) {
+						B = W;
+						onA = W.merge != OTZ_K1_NONE;
+						cm = onA ? W.merge : 0u;
+						exit_cur = onA ? A.exit : W.exit;
+					}
+				}
+				if (moved && !rewalk) { // lands on walk A's first token: confirmed as it stands
+					B.n = B.bytes = B.nck = 0;
+					onA = true;
+					cm = 0;
+					exit_cur = A.exit;
+				}
+				if (otz_ballot (moved && exit_cur != old_exit) == 0) {
+					break;
+				}
+			}
+			// ---- acceptance: lanes up to the first one whose path does not simply run on
+			const u64 termm = otz_ballot (OTZ_X_KIND (exit_cur) != OTZ_X_NORMAL);
+			const u32 F = termm ? otz_ctz64 (termm) : 63u; // last accepted lane
+			const bool acc = lane <= F;
+			// tokens of walk A before checkpoint cm are not on the true path
+			const u32 offA = onA && cm ? rowsA[cm * 64u + lane].out : 0u;
+			const u32 nA_items = onA ? (A.n + OTZ_IX_G - 1u) / OTZ_IX_G : 0u;
+			const u32 nB_items = (B.n + OTZ_IX_G - 1u) / OTZ_IX_G;
+			const u32 cnt = acc ? nB_items + (onA && nA_items > cm ? nA_items - cm : 0u) : 0u;
+			const u32 bytes = acc ? B.bytes + (onA ? A.bytes - offA : 0u) : 0u;
+			const u32 bincl = otz_wave_scan_incl (bytes);
+			const u32 cincl = otz_wave_scan_incl (cnt);
+			const u32 produced = otz_readlane (bincl, 63u), n_new = otz_readlane (cincl, 63u);
+			const u32 fkind = OTZ_X_KIND (otz_readlane (exit_cur, F));
+			// the stream wants more than uncomp_size bytes (ref: pending copy/literal, Z_OK) --
+			// unless it breaks before that point
+			const u32 room = out_cap - opos;
+			const u64 overm = otz_ballot (acc && bincl > room);
+			if (overm != 0) {
+				status = OTZ_K1_ST_NEED_OUT;
+				break;
+			}
+			if (fkind == OTZ_X_INVALID || fkind == OTZ_X_TRUNC) {
+				status = OZG_ST_DATA; // ref: Z_DATA_ERROR from get_bit / no matching code
+				break;
+			}
+			if (n_items + n_new + 1u > items_cap) {
+				status = OTZ_IX_OVERFLOW;
+				break;
+			}
+			// ---- the accepted lanes' items, in stream order
+			{
+				// block-relative bit position of this lane's slot bit 0
+				const u32 bit0 = (u32) ((u64) (8 * slot0) - block_bit);
+				const u32 obase = opos - block_out + bincl - bytes;
+				otz_ix_item *dst = items + n_items + (cincl - cnt);
+				const u32 maxc = 2u * OTZ_K1_ROWS;
+				for (u32 k = 0; k < maxc; k++) {
+					if (otz_ballot (k < cnt) == 0) {
+						break;
+					}
+					if (k < cnt) {
+						otz_ix_item it;
+						if (k < nB_items) {
+							it = rowsB[k * 64u + lane];
+						} else {
+							it = rowsA[(cm + k - nB_items) * 64u + lane];
+							it.out = it.out - offA + B.bytes;
+						}
+						it.bit += bit0;
+						it.out += obase;
+						dst[k] = it;
+					}
+				}
+			}
+			n_items += n_new;
+			opos += produced;
+			// where the stream goes on (lane F's exit), and how the block ends
+			const u32 fexit = otz_readlane (exit_cur, F);
+			const u32 ftstart = otz_readlane (onA ? A.tstart : B.tstart, F);
+			const u64 fslot_bit = (u64) (8 * ((int64_t)rb + 64 * (int64_t)F - (int64_t) (OTZ_K1_WARM / 8u)));
+			abs_bit = fslot_bit + OTZ_X_POS (fexit);
+			if (fkind == OTZ_X_EOB) {
+				block_done = true;
+				eob_abs = fslot_bit + ftstart;
+				end_bit = (u32) (eob_abs - block_bit);
+			} else {
+				end_bit = (u32) (abs_bit - block_bit);
+			}
+		}
+		if (status != 0) {
+			break;
+		}
+		if (lane == 0) {
+			otz_ix_item sent;
+			sent.bit = end_bit;
+			sent.out = opos - block_out;
+			items[n_items] = sent;
+			blk->kind = OTZ_IX_KIND_HUFF;
+			blk->n_items = n_items;
+			blk->bit_lo = (u32)block_bit;
+			blk->bit_hi = (u32) (block_bit >> 32);
+			blk->out_base = block_out;
+			blk->out_len = opos - block_out;
+			blk->hlit_hdist = hlit | (hdist << 16);
+			blk->next = 0;
+			if (prev_next_at) {
+				*reinterpret_cast<u32 *> (region + prev_next_at) = rec;
+			}
+		}
+		prev_next_at = rec + 28u;
+		rec += (OTZ_IX_ITEMS_OFF + 8u * (n_items + 1u) + 31u) & ~31u;
+		n_blocks++;
+		ended = last_block;
+	}
+
+	if (status == 0 && last_btype != 0) {
+		// the reference returns Z_BUF_ERROR when every input byte had already
+		// been loaded before the step that decodes the final EOB
+		if (((eob_abs + 7u) >> 3) >= (u64)n_in) {
+			flags |= OZG_F_REF_FALSE_REJECT;
+		}
+	}
+	if (lane == 0) {
+		head->status = status == OTZ_K1_ST_NEED_OUT ? OTZ_K1_ST_NEED_OUT : status;
+		head->total_out = opos;
+		head->flags = flags;
+		head->n_blocks = n_blocks;
+		head->first_block = 32u;
+		head->dbg[0] = head->dbg[1] = head->dbg[2] = 0;
+	}
+	return status == OTZ_IX_OVERFLOW;
+}

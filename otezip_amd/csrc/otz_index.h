@@ -1,0 +1,74 @@
+// otz_index.h -- the hand-off between the two halves of the DEFLATE decode.
+//
+// Raw DEFLATE is one serial chain of variable-length tokens, and the LZ77 window needs
+// 32 KiB of fast memory per stream.  Those two facts want opposite launch shapes, so the
+// decode of an entry is split (ref path: inflate(), src/lib/deflate-dec.inc.c:547-831):
+//
+//   otz_index_kernel (otz_huff_index.h): ONE WAVEFRONT per entry, no workgroup barriers,
+//     12 KB of LDS -> many entries per CU.  It finds the token chain -- where every token
+//     starts and how many output bytes precede it -- and writes that down as an INDEX:
+//     per DEFLATE block the code lengths and a flat list of items, one every <= OTZ_IX_G
+//     tokens: (bit position, output position).  It produces no output bytes.
+//   otz_apply_kernel (otz_lz_apply.h): one 512-lane workgroup per entry with the 56 KiB
+//     LDS ring.  With the index every lane starts at an exact token boundary with an exact
+//     output position: no speculation, no fixpoint, and every lane decodes the same number
+//     of tokens.  It places literals, resolves the LZ77 copies in LDS, takes the CRC-32
+//     and streams the bytes out.
+//
+// The index lives in a device arena the library owns (one region per entry, carved by
+// otz_plan_kernel).  An entry whose index does not fit its region (pathological streams:
+// thousands of empty blocks, ...) is marked OTZ_IX_OVERFLOW and the apply kernel decodes
+// it with the self-contained workgroup-per-entry routine of otz_inflate.h instead.
+#pragma once
+
+#include "otz_simt.h"
+
+#define OTZ_IX_G 8u          // tokens per item
+#define OTZ_IX_OVERFLOW 77   // head.status: index did not fit; decode with otz_inflate_entry
+#define OTZ_IX_KIND_STORED 0u
+#define OTZ_IX_KIND_HUFF 1u
+#define OTZ_IX_LENS 320u     // code lengths stored per Huffman block (288 + 32)
+
+// first 32 bytes of an entry's region
+struct otz_ix_head {
+	int32_t status;  // 0: index complete, the apply kernel decodes; OTZ_IX_OVERFLOW; else the entry's final status
+	u32 total_out;   // bytes the stream produces (status 0), or bytes produced before the failure
+	u32 flags;       // OZG_F_REF_FALSE_REJECT
+	u32 n_blocks;
+	u32 first_block; // region offset of the first block record
+	u32 dbg[3];
+};
+
+// block record: header, then (Huffman blocks) OTZ_IX_LENS code-length bytes and n_items + 1 items
+struct otz_ix_block {
+	u32 kind;
+	u32 n_items;        // Huffman: items, not counting the end sentinel
+	u32 bit_lo, bit_hi; // Huffman: entry bit position that item.bit is relative to; stored: source byte offset
+	u32 out_base;       // output position of the block's first byte
+	u32 out_len;        // bytes the block produces
+	u32 hlit_hdist;     // hlit | hdist << 16
+	u32 next;           // region offset of the next block record
+};
+
+// One item: the token that starts at bit `bit` (relative to the block's bit base) writes its
+// first byte at output position `out` (relative to the block's out_base).  An item ends where
+// the next one starts; the list is closed by a sentinel (bit = start of the end-of-block
+// code, out = out_len).
+struct otz_ix_item {
+	u32 bit;
+	u32 out;
+};
+
+#define OTZ_IX_ITEMS_OFF (32u + OTZ_IX_LENS)
+
+// what a region must hold besides the records: the speculative checkpoint rows of the index
+// kernel (two walks x OTZ_K1_ROWS rows x 64 lanes x 8 bytes), at the region's end
+#define OTZ_K1_ROWS 12u
+#define OTZ_K1_TEMP_BYTES (2u * OTZ_K1_ROWS * 64u * 8u)
+
+// bytes of arena an entry asks for: records for one item per OTZ_IX_G output bytes in the
+// worst case (a stream of literals), one lane head per 64 bytes of input, block records, temp
+OTZ_DEV u64 otz_ix_region_bytes(u32 comp_size, u32 uncomp_size) {
+	u64 b = (u64)uncomp_size + (comp_size >> 1) + 4096u + OTZ_K1_TEMP_BYTES;
+	return (b + 255u) & ~(u64)255u;
+}

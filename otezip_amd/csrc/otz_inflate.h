@@ -216,11 +216,6 @@ struct otz_tok {
 	u32 dist;
 };
 
-struct otz_dec {
-	u32 unused;
-};
-OTZ_DEV void otz_dec_load(otz_dec &D, const otz_inflate_lds &L) { D.unused = 0; }
-
 // Table entries: code length in bits 0-3, OTZ_K_* in bits 4-5, extra-bit count in bits
 // 8-11, value (literal, length base, distance base) in bits 16+.  A slot no code maps to is
 // OTZ_LUT_NONE (kind BAD, length 0); a root slot whose codes are longer than the root is a
@@ -241,7 +236,8 @@ OTZ_DEV u32 otz_lut2(const u32 *lut, u32 bits) {
 // at bit 0 of (hi:lo): 64 stream bits always cover a whole token (at most
 // 15+5+15+13 = 48 bits).  (Fetching them with one unaligned 8-byte LDS read instead
 // of aligned words measured slower.)
-OTZ_DEV otz_tok otz_decode_bits(const otz_inflate_lds &L, u32 lo, u32 hi) {
+template <class LDS>
+OTZ_DEV otz_tok otz_decode_bits(const LDS &L, u32 lo, u32 hi) {
 	otz_tok t;
 	u32 e = otz_lut2<OTZ_LIT_ROOT> (L.lit_lut, lo);
 	u32 len = e & 15u;
@@ -895,7 +891,7 @@ struct otz_path {
 // matches (a match is at least two bits): a lane's path yields < 64 * 258 + 64 bytes,
 // which always fits a round (OTZ_RMAX) and a u16 note.
 template <int MODE>
-OTZ_DEV otz_path otz_walk(otz_inflate_lds &L, const otz_dec &D, u32 start, u32 s, u32 e, u32 limit_bits, u32 stop, otz_vis &vis, u16 *notes = nullptr, u32 note_cap = 0) {
+OTZ_DEV otz_path otz_walk(otz_inflate_lds &L, u32 start, u32 s, u32 e, u32 limit_bits, u32 stop, otz_vis &vis, u16 *notes = nullptr, u32 note_cap = 0) {
 	otz_path P;
 	u32 pos = start, ntok = 0, bytes = 0;
 	const u32 end = MODE == OTZ_MODE_PREFIX ? stop : e;
@@ -994,7 +990,7 @@ OTZ_DEV bool otz_all_final(const otz_inflate_lds &L, u32 a, u32 b) {
 // own destination (a match is at least three bytes long, so the space is always
 // there), and the destination's bit is set in the match-start bitmap.  No lane
 // waits for another lane in this pass.
-OTZ_DEV void otz_place(otz_inflate_lds &L, const otz_dec &D, bool active, u32 start, u32 exit_word, u32 o, u32 round_base, u64 stage_abs_bit) {
+OTZ_DEV void otz_place(otz_inflate_lds &L, bool active, u32 start, u32 exit_word, u32 o, u32 round_base, u64 stage_abs_bit) {
 	if (!active) {
 		return;
 	}
@@ -1372,8 +1368,6 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 			break;
 		}
 
-		otz_dec D;
-		otz_dec_load (D, L);
 		OTZ_MARK (L, J, OTZ_P_TABLES);
 		// ---- rounds over the block's symbols
 		bool block_done = false;
@@ -1420,7 +1414,7 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 			// tokens, so by the time the path reaches s it is usually already the true
 			// one, and pass B's walk meets it at its first token.
 			const u32 a_start = tid ? s - OTZ_WARM_BITS : s;
-			otz_path A = otz_walk<OTZ_MODE_A> (L, D, a_start, s, e, limit_bits, 0, vis, notes, note_cap);
+			otz_path A = otz_walk<OTZ_MODE_A> (L, a_start, s, e, limit_bits, 0, vis, notes, note_cap);
 			L.exits[tid] = A.exit;
 			otz_sync ();
 
@@ -1448,7 +1442,7 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 				bool changed = false;
 				if (tid && OTZ_X_KIND (prev) == OTZ_X_NORMAL && OTZ_X_POS (prev) != t) {
 					t = OTZ_X_POS (prev);
-					otz_path B = otz_walk<OTZ_MODE_B> (L, D, t, s, e, limit_bits, 0, vis);
+					otz_path B = otz_walk<OTZ_MODE_B> (L, t, s, e, limit_bits, 0, vis);
 					wbytes = B.bytes;
 					q = B.syncq;
 					u32 ne = q != ~0u ? A.exit : B.exit;
@@ -1485,7 +1479,7 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 							// re-walk pass A's recorded path from its first token
 							otz_vis dummy = { 0, 0 };
 							const u32 first = s + (vis.lo ? otz_ctz64 (vis.lo) : 64u + otz_ctz64 (vis.hi));
-							pre = otz_walk<OTZ_MODE_PREFIX> (L, D, first, s, e, limit_bits, q, dummy).bytes;
+							pre = otz_walk<OTZ_MODE_PREFIX> (L, first, s, e, limit_bits, q, dummy).bytes;
 						}
 					}
 					bytes = wbytes + A.bytes - pre;
@@ -1538,7 +1532,7 @@ OTZ_DEV void otz_inflate_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_
 				L.mstart[i] = 0;
 			}
 			otz_sync ();
-			otz_place (L, D, tid < K, tid == 0 ? s : t, my_exit, opos + incl - bytes, opos, stage_abs);
+			otz_place (L, tid < K, tid == 0 ? s : t, my_exit, opos + incl - bytes, opos, stage_abs);
 			otz_sync ();
 			OTZ_MARK (L, J, OTZ_P_EMIT);
 			if (otz_get_status (L) != 0) {

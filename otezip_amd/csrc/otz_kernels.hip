@@ -1,9 +1,16 @@
 // otz_kernels.hip -- gfx950 kernels and the ozg_* C ABI (include/otezip_gpu.h).
 //
-// Decode kernels, one workgroup per archive entry:
-//   otz_inflate_kernel  DEFLATE entries; 512 lanes (8 wavefronts), 77 KB of LDS per
-//                       workgroup -> two resident workgroups per CU (160 KB LDS,
-//                       <= 128 VGPRs), 512 entries in flight on the chip
+// Decode kernels:
+//   otz_plan_kernel     one work-item per entry: checks the descriptor against the buffers
+//                       and carves the entry's region of the index arena
+//   otz_index_kernel    DEFLATE entries, first half: ONE WAVEFRONT per entry finds the token
+//                       chain and writes the index (otz_huff_index.h); 12 KB of LDS
+//   otz_apply_kernel    DEFLATE entries, second half: 512 lanes (8 wavefronts), 77 KB of
+//                       LDS per workgroup -> two resident workgroups per CU (<= 128 VGPRs);
+//                       index -> bytes, LZ77 in LDS, CRC-32 (otz_lz_apply.h)
+//   otz_inflate_kernel  the self-contained workgroup-per-entry DEFLATE decode (otz_inflate.h)
+//                       for the entries whose index overflowed its arena region: a small
+//                       persistent grid over the overflow list, normally empty
 //   otz_copy_kernel     STORE and the private raw framings; 256 lanes, 11 KB of LDS
 // Encode kernels, one buffer each: otz_encode_kernel (one wavefront: DEFLATE, the private
 // framings' writers, STORE) and otz_enc_crc_kernel (CRC-32 of the input).
@@ -28,24 +35,96 @@ static_assert (sizeof (ozg_enc_entry) == 32 && sizeof (ozg_enc_result) == 16, "e
 static_assert (sizeof (otz_inflate_lds) <= 80 * 1024, "two inflate workgroups per CU");
 
 static_assert (OTZ_NT * OTZ_S_BITS / 8 + 512 <= OTZ_STAGE_BYTES, "stage must cover one round of input");
+static_assert (sizeof (otz_ix_head) == 32 && sizeof (otz_ix_block) == 32 && sizeof (otz_ix_item) == 8, "index layout");
+
+struct otz_region {
+	u64 off;   // byte offset into the index arena
+	u32 bytes; // 0: none (descriptor out of bounds, not DEFLATE, or the arena is full)
+	u32 pad;
+};
+
+extern "C" __global__ void __launch_bounds__ (256)
+otz_plan_kernel(const ozg_entry *entries, u32 n, u64 src_len, u64 dst_len, u64 arena_cap, unsigned long long *cursor, otz_region *regions, otz_ix_head *heads) {
+	const u32 i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) {
+		return;
+	}
+	const ozg_entry e = entries[i];
+	otz_region r = { 0, 0, 0 };
+	if (e.method == OZG_METHOD_DEFLATE && otz_entry_in_bounds (e, src_len, dst_len)) {
+		const u64 want = otz_ix_region_bytes (e.comp_size, e.uncomp_size);
+		if (want <= 0xFFFFFF00ull) {
+			const u64 off = atomicAdd (cursor, (unsigned long long)want);
+			if (off + want <= arena_cap) {
+				r.off = off;
+				r.bytes = (u32)want;
+			}
+		}
+	}
+	regions[i] = r;
+	heads[i].status = OTZ_IX_OVERFLOW; // until the index kernel says otherwise
+}
+
+// One wavefront per entry, no workgroup barrier anywhere: the number of entries in flight
+// per CU is set by LDS (12 KB each) and registers alone.
+extern "C" __global__ void __launch_bounds__ (64)
+__attribute__ ((amdgpu_waves_per_eu (3, 8)))
+otz_index_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, u32 n, u64 src_len, u64 dst_len, ozg_limits lim, u8 *arena, const otz_region *regions, otz_ix_head *heads,
+	u32 *ovf) {
+	extern __shared__ __attribute__ ((aligned (16))) u8 otz_smem[];
+	const u32 i = blockIdx.x;
+	if (i >= n) {
+		return;
+	}
+	otz_k1_lds &L = *reinterpret_cast<otz_k1_lds *> (otz_smem);
+	const ozg_entry e = entries[i];
+	if (!otz_entry_in_bounds (e, src_len, dst_len)) {
+		return;
+	}
+	const otz_region r = regions[i];
+	if (otz_run_index (L, src, dst, e, lim, &heads[i], arena + r.off, r.bytes) && otz_lane () == 0) {
+		ovf[1u + atomicAdd (&ovf[0], 1u)] = i; // ovf[0]: count, then the entries
+	}
+}
+
+extern "C" __global__ void __launch_bounds__ (OTZ_NT) __attribute__ ((amdgpu_waves_per_eu (4, 4)))
+otz_inflate_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *results, ozg_limits lim, const u32 *ovf) {
+	extern __shared__ __attribute__ ((aligned (16))) u8 otz_smem[];
+	otz_inflate_lds &L = *reinterpret_cast<otz_inflate_lds *> (otz_smem);
+	const u32 count = ovf[0];
+	for (u32 k = blockIdx.x; k < count; k += gridDim.x) {
+		const u32 i = ovf[1u + k];
+		const ozg_entry e = entries[i];
+		otz_sync ();
+		otz_run_inflate (L, src, dst, e, &results[i], lim, nullptr);
+	}
+}
 
 // Two workgroups per CU (16 waves, 4 per SIMD) need <= 128 VGPRs: pin that occupancy so a
 // register-hungry change fails the resource check in tests/test_abi.py instead of
 // silently halving the number of entries in flight.
 extern "C" __global__ void __launch_bounds__ (OTZ_NT) __attribute__ ((amdgpu_waves_per_eu (4, 4)))
-otz_inflate_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *results, u32 n, ozg_limits lim, u64 *prof) {
+otz_apply_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *results, u32 n, u64 src_len, u64 dst_len, ozg_limits lim,
+	const u8 *arena, const otz_region *regions, const otz_ix_head *heads, u64 *prof) {
 	extern __shared__ __attribute__ ((aligned (16))) u8 otz_smem[];
-	u32 i = blockIdx.x;
+	const u32 i = blockIdx.x;
 	if (i >= n) {
 		return;
 	}
 	otz_inflate_lds &L = *reinterpret_cast<otz_inflate_lds *> (otz_smem);
-	ozg_entry e = entries[i];
-	otz_run_inflate (L, src, dst, e, &results[i], lim, prof ? prof + 16ull * i : nullptr);
+	const ozg_entry e = entries[i];
+	if (e.method != OZG_METHOD_DEFLATE) {
+		return;
+	}
+	if (!otz_entry_in_bounds (e, src_len, dst_len)) {
+		otz_fail (&results[i], OZG_ST_INTERNAL);
+		return;
+	}
+	otz_run_apply (L, src, dst, e, &results[i], lim, &heads[i], arena + regions[i].off, prof ? prof + 16ull * i : nullptr);
 }
 
 extern "C" __global__ void __launch_bounds__ (256)
-otz_copy_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *results, u32 n, ozg_limits lim) {
+otz_copy_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *results, u32 n, u64 src_len, u64 dst_len, ozg_limits lim) {
 	extern __shared__ __attribute__ ((aligned (16))) u8 otz_smem[];
 	u32 i = blockIdx.x;
 	if (i >= n) {
@@ -53,6 +132,13 @@ otz_copy_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *re
 	}
 	otz_copy_lds &L = *reinterpret_cast<otz_copy_lds *> (otz_smem);
 	ozg_entry e = entries[i];
+	if (e.method == OZG_METHOD_DEFLATE) {
+		return;
+	}
+	if (!otz_entry_in_bounds (e, src_len, dst_len)) {
+		otz_fail (&results[i], OZG_ST_INTERNAL);
+		return;
+	}
 	otz_run_copy (L, src, dst, e, &results[i], lim);
 }
 
@@ -123,6 +209,7 @@ otz_enc_crc_kernel(const u8 *src, u8 *dst, const ozg_enc_entry *entries, ozg_enc
 namespace {
 
 std::mutex g_mu;
+std::mutex g_ws_mu;
 bool g_ready = false;
 int g_device = -1;
 ozg_limits g_limits = { 1000ull, 1024ull * 1024ull };
@@ -133,6 +220,20 @@ struct staging {
 	void *d_src = nullptr, *d_dst = nullptr, *d_ent = nullptr, *d_res = nullptr;
 	size_t src_cap = 0, dst_cap = 0, ent_cap = 0, res_cap = 0;
 } g_stage;
+
+// Index arena of the DEFLATE path.  One per library (device); batches on different streams
+// are ordered through `done`.
+struct workspace {
+	u8 *arena = nullptr;
+	size_t arena_cap = 0;
+	otz_region *regions = nullptr;
+	otz_ix_head *heads = nullptr;
+	size_t n_cap = 0;
+	unsigned long long *cursor = nullptr;
+	u32 *ovf = nullptr; // overflow list: count, then entry numbers
+	hipEvent_t done = nullptr;
+	bool busy = false;
+} g_ws;
 
 int fail_hip(const char *what, hipError_t e) {
 	snprintf (g_err, sizeof (g_err), "%s: %s", what, hipGetErrorString (e));
@@ -198,8 +299,12 @@ int ozg_init(int device) {
 		return OZG_E_ARG;
 	}
 	OZG_HIP (hipSetDevice (device));
+	OZG_HIP (hipFuncSetAttribute ((const void *)otz_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+		(int)sizeof (otz_inflate_lds)));
 	OZG_HIP (hipFuncSetAttribute ((const void *)otz_inflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
 		(int)sizeof (otz_inflate_lds)));
+	OZG_HIP (hipFuncSetAttribute ((const void *)otz_index_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+		(int)sizeof (otz_k1_lds)));
 	OZG_HIP (hipFuncSetAttribute ((const void *)otz_copy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
 		(int)sizeof (otz_copy_lds)));
 	OZG_HIP (hipFuncSetAttribute ((const void *)otz_crc32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -233,6 +338,25 @@ void ozg_shutdown(void) {
 		(void)hipFree (g_stage.d_res);
 	}
 	g_stage = staging ();
+	if (g_ws.arena) {
+		(void)hipFree (g_ws.arena);
+	}
+	if (g_ws.regions) {
+		(void)hipFree (g_ws.regions);
+	}
+	if (g_ws.heads) {
+		(void)hipFree (g_ws.heads);
+	}
+	if (g_ws.cursor) {
+		(void)hipFree (g_ws.cursor);
+	}
+	if (g_ws.ovf) {
+		(void)hipFree (g_ws.ovf);
+	}
+	if (g_ws.done) {
+		(void)hipEventDestroy (g_ws.done);
+	}
+	g_ws = workspace ();
 	g_ready = false;
 }
 
@@ -242,14 +366,63 @@ void ozg_set_limits(const ozg_limits *lim) {
 	}
 }
 
+// Room for the index of a batch: every entry asks for otz_ix_region_bytes(); their sum is
+// bounded by the buffer sizes (dst regions do not overlap).  Entries that find the arena
+// full are decoded by the apply kernel's self-contained routine instead.
+static int ws_reserve(uint64_t src_len, uint64_t dst_len, uint32_t n) {
+	const size_t per_entry = 4096u + OTZ_K1_TEMP_BYTES + 256u;
+	size_t want = (size_t)dst_len + (size_t) (src_len >> 1) + (size_t)n * per_entry;
+	if (want > ((size_t)8 << 30)) {
+		want = (size_t)8 << 30; // beyond that, the overflow path takes what does not fit
+	}
+	if (!g_ws.done) {
+		OZG_HIP (hipEventCreateWithFlags (&g_ws.done, hipEventDisableTiming));
+	}
+	if (!g_ws.cursor) {
+		OZG_HIP (hipMalloc ((void **)&g_ws.cursor, 256));
+	}
+	if (want > g_ws.arena_cap || n > g_ws.n_cap) {
+		OZG_HIP (hipDeviceSynchronize ()); // earlier batches may still read what is about to be freed
+		g_ws.busy = false;
+	}
+	if (want > g_ws.arena_cap) {
+		if (g_ws.arena) {
+			(void)hipFree (g_ws.arena);
+			g_ws.arena = nullptr;
+			g_ws.arena_cap = 0;
+		}
+		OZG_HIP (hipMalloc ((void **)&g_ws.arena, want));
+		g_ws.arena_cap = want;
+	}
+	if (n > g_ws.n_cap) {
+		if (g_ws.regions) {
+			(void)hipFree (g_ws.regions);
+			g_ws.regions = nullptr;
+		}
+		if (g_ws.heads) {
+			(void)hipFree (g_ws.heads);
+			g_ws.heads = nullptr;
+		}
+		if (g_ws.ovf) {
+			(void)hipFree (g_ws.ovf);
+			g_ws.ovf = nullptr;
+		}
+		g_ws.n_cap = 0;
+		const size_t cap = n < 1024u ? 1024u : n;
+		OZG_HIP (hipMalloc ((void **)&g_ws.regions, cap * sizeof (otz_region)));
+		OZG_HIP (hipMalloc ((void **)&g_ws.heads, cap * sizeof (otz_ix_head)));
+		OZG_HIP (hipMalloc ((void **)&g_ws.ovf, (cap + 1u) * sizeof (u32)));
+		g_ws.n_cap = cap;
+	}
+	return OZG_OK;
+}
+
 int ozg_decode_batch_device_ex(const void *d_src, uint64_t src_len, void *d_dst, uint64_t dst_len,
 	const ozg_entry *d_entries, ozg_result *d_results, uint32_t n, void *stream, uint32_t batch_flags) {
 	int rc = need_ready ();
 	if (rc != OZG_OK) {
 		return rc;
 	}
-	(void)src_len;
-	(void)dst_len;
 	if (n == 0) {
 		return OZG_OK;
 	}
@@ -263,13 +436,33 @@ int ozg_decode_batch_device_ex(const void *d_src, uint64_t src_len, void *d_dst,
 	}
 	hipStream_t s = (hipStream_t)stream;
 	if (!(batch_flags & OZG_BATCH_NO_DEFLATE)) {
-		hipLaunchKernelGGL (otz_inflate_kernel, dim3 (n), dim3 (OTZ_NT), sizeof (otz_inflate_lds), s, (const u8 *)d_src,
-			(u8 *)d_dst, d_entries, d_results, n, g_limits, g_prof);
+		std::lock_guard<std::mutex> lk (g_ws_mu);
+		if ((rc = ws_reserve (src_len, dst_len, n)) != OZG_OK) {
+			return rc;
+		}
+		if (g_ws.busy) {
+			OZG_HIP (hipStreamWaitEvent (s, g_ws.done, 0)); // the arena is shared between streams
+		}
+		OZG_HIP (hipMemsetAsync (g_ws.cursor, 0, 8, s));
+		OZG_HIP (hipMemsetAsync (g_ws.ovf, 0, 4, s));
+		hipLaunchKernelGGL (otz_plan_kernel, dim3 ((n + 255u) / 256u), dim3 (256), 0, s, d_entries, n, (u64)src_len, (u64)dst_len,
+			(u64)g_ws.arena_cap, g_ws.cursor, g_ws.regions, g_ws.heads);
 		OZG_HIP (hipGetLastError ());
+		hipLaunchKernelGGL (otz_index_kernel, dim3 (n), dim3 (64), sizeof (otz_k1_lds), s, (const u8 *)d_src, (u8 *)d_dst, d_entries, n,
+			(u64)src_len, (u64)dst_len, g_limits, g_ws.arena, g_ws.regions, g_ws.heads, g_ws.ovf);
+		OZG_HIP (hipGetLastError ());
+		hipLaunchKernelGGL (otz_apply_kernel, dim3 (n), dim3 (OTZ_NT), sizeof (otz_inflate_lds), s, (const u8 *)d_src, (u8 *)d_dst,
+			d_entries, d_results, n, (u64)src_len, (u64)dst_len, g_limits, (const u8 *)g_ws.arena, g_ws.regions, g_ws.heads, g_prof);
+		OZG_HIP (hipGetLastError ());
+		hipLaunchKernelGGL (otz_inflate_kernel, dim3 (n < 256u ? n : 256u), dim3 (OTZ_NT), sizeof (otz_inflate_lds), s, (const u8 *)d_src,
+			(u8 *)d_dst, d_entries, d_results, g_limits, (const u32 *)g_ws.ovf);
+		OZG_HIP (hipGetLastError ());
+		OZG_HIP (hipEventRecord (g_ws.done, s));
+		g_ws.busy = true;
 	}
 	if (!(batch_flags & OZG_BATCH_ONLY_DEFLATE)) {
 		hipLaunchKernelGGL (otz_copy_kernel, dim3 (n), dim3 (256), sizeof (otz_copy_lds), s, (const u8 *)d_src,
-			(u8 *)d_dst, d_entries, d_results, n, g_limits);
+			(u8 *)d_dst, d_entries, d_results, n, (u64)src_len, (u64)dst_len, g_limits);
 		OZG_HIP (hipGetLastError ());
 	}
 	return OZG_OK;
@@ -491,7 +684,8 @@ int ozg_stream_sync(void *stream) {
  * per-phase cycle counts of every entry (NULL switches it off). */
 void ozg_debug_set_profile_buffer(void *d_buf) { g_prof = (u64 *)d_buf; }
 
-const char *ozg_kernel_name_inflate(void) { return "otz_inflate_kernel"; }
+const char *ozg_kernel_name_inflate(void) { return "otz_apply_kernel"; }
+const char *ozg_kernel_name_index(void) { return "otz_index_kernel"; }
 const char *ozg_kernel_name_copy(void) { return "otz_copy_kernel"; }
 
 } // extern "C"

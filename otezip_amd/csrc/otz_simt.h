@@ -51,6 +51,10 @@ OTZ_DEV u64 otz_ballot(bool p) { return __ballot (p); }
 OTZ_DEV u32 otz_shfl_up(u32 v, u32 d) { return (u32)__shfl_up ((int)v, d, 64); }
 OTZ_DEV u32 otz_shfl(u32 v, u32 src) { return (u32)__shfl ((int)v, (int)src, 64); }
 OTZ_DEV u32 otz_shfl_xor(u32 v, u32 m) { return (u32)__shfl_xor ((int)v, (int)m, 64); }
+// value of lane `src`, where src is the same in every lane: v_readlane_b32 (no LDS round trip)
+OTZ_DEV u32 otz_readlane(u32 v, u32 src) { return (u32)__builtin_amdgcn_readlane ((int)v, (int)__builtin_amdgcn_readfirstlane ((int)src)); }
+// a value known to be the same in every lane, moved to a scalar register
+OTZ_DEV u32 otz_uniform(u32 v) { return (u32)__builtin_amdgcn_readfirstlane ((int)v); }
 
 // LDS atomics (workgroup scope)
 OTZ_DEV void otz_lds_or(u32 *p, u32 v) { __hip_atomic_fetch_or (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -82,6 +86,7 @@ OTZ_DEV u32 otz_popc64(u64 v) { return (u32)__popcll (v); }
 OTZ_DEV u32 otz_brev(u32 v) { return __brev (v); }
 OTZ_DEV u32 otz_ctz(u32 v) { return (u32)__builtin_ctz (v); }
 OTZ_DEV u32 otz_ctz64(u64 v) { return (u32)__builtin_ctzll (v); }
+OTZ_DEV u32 otz_clz64(u64 v) { return (u32)__builtin_clzll (v); }
 // width (<32) bits of v starting at bit off: v_bfe_u32
 OTZ_DEV u32 otz_bfe(u32 v, u32 off, u32 width) { return __builtin_amdgcn_ubfe (v, off, width); }
 // low 32 bits of (hi:lo) >> (sh & 31): v_alignbit_b32

@@ -75,18 +75,23 @@ def emu_lib():
         L.emu_decode_batch.restype = C.c_int
         L.emu_decode_batch.argtypes = [C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(OzgEntry),
                                        C.POINTER(OzgResult), C.c_uint32, C.c_uint64, C.c_uint64]
+        L.emu_decode_batch_mode.restype = C.c_int
+        L.emu_decode_batch_mode.argtypes = L.emu_decode_batch.argtypes + [C.c_int, C.c_uint32]
+        L.emu_lds_bytes_index.restype = C.c_uint32
         L.emu_lds_bytes_inflate.restype = C.c_uint32
         L.emu_lds_bytes_copy.restype = C.c_uint32
         _emu = L
     return _emu
 
 
-def emu_decode(items, ratio=1000, slack=1 << 20):
-    """Run items through the emulated kernels. Returns [(OzgResult, out_bytes)]."""
+def emu_decode(items, ratio=1000, slack=1 << 20, mode=0, region_pct=100):
+    """Run items through the emulated kernels. Returns [(OzgResult, out_bytes)].
+    mode 0: product path (index + apply kernels); 1: the workgroup-per-entry routine alone;
+    2: product path without arena regions (forces the in-kernel fallback)."""
     src, ents, dst_len = layout(items)
     dst = C.create_string_buffer(b"\xCD" * dst_len, dst_len)
     res = (OzgResult * max(len(items), 1))()
-    emu_lib().emu_decode_batch(src, len(src), dst, dst_len, ents, res, len(items), ratio, slack)
+    emu_lib().emu_decode_batch_mode(src, len(src), dst, dst_len, ents, res, len(items), ratio, slack, mode, region_pct)
     out = []
     for i, it in enumerate(items):
         o = ents[i].dst_off

@@ -24,6 +24,71 @@ struct otz_u4 {
 	u32 x, y, z, w;
 };
 
+#ifndef OTZ_EMU_PTHREADS
+// Default: one OS thread per WAVEFRONT, its 64 work-items are cooperative fibers
+// (ucontext) that switch at every wave-level operation.  A wave barrier costs 64 user-space
+// context switches instead of 64 futex waits, which makes the emulation ~10x faster.
+// -DOTZ_EMU_PTHREADS (the sanitizer build) keeps one OS thread per work-item.
+#include <ucontext.h>
+
+struct otz_emu_wave {
+	ucontext_t sched;        // the wave's OS thread
+	ucontext_t fib[64];
+	unsigned char done[64];
+	u32 nfib, alive, cur;
+	u32 bar_count, bar_gen;
+	void *stacks;
+};
+
+struct otz_emu_block {
+	u32 nthreads;
+	pthread_barrier_t block_bar; // one participant per wavefront
+	otz_emu_wave wave[16];
+	u32 xchg[1024];
+};
+
+struct otz_emu_thread {
+	u32 tid;
+	otz_emu_block *blk;
+};
+
+extern thread_local otz_emu_thread otz_emu_self;
+
+// switch to the next live fiber of this wave (round robin); returns when this one is resumed
+void otz_emu_yield();
+
+OTZ_DEV void otz_emu_wave_sync() {
+	otz_emu_wave &w = otz_emu_self.blk->wave[otz_emu_self.tid >> 6];
+	const u32 gen = w.bar_gen;
+	if (++w.bar_count >= w.alive) {
+		w.bar_count = 0;
+		w.bar_gen = gen + 1u;
+		return;
+	}
+	while (w.bar_gen == gen) {
+		otz_emu_yield ();
+	}
+}
+OTZ_DEV void otz_wave_sync() { otz_emu_wave_sync (); }
+// workgroup barrier: every wave gathers its fibers, ONE fiber per wave meets the other
+// waves' OS threads, then the wave's fibers are released together
+OTZ_DEV void otz_sync() {
+	otz_emu_wave &w = otz_emu_self.blk->wave[otz_emu_self.tid >> 6];
+	const u32 gen = w.bar_gen;
+	if (++w.bar_count >= w.alive) {
+		pthread_barrier_wait (&otz_emu_self.blk->block_bar);
+		w.bar_count = 0;
+		w.bar_gen = gen + 1u;
+		return;
+	}
+	while (w.bar_gen == gen) {
+		otz_emu_yield ();
+	}
+}
+OTZ_DEV void otz_backoff() { otz_emu_yield (); }
+
+#else
+
 struct otz_emu_block {
 	u32 nthreads;
 	pthread_barrier_t block_bar;
@@ -38,14 +103,17 @@ struct otz_emu_thread {
 
 extern thread_local otz_emu_thread otz_emu_self;
 
+OTZ_DEV void otz_sync() { pthread_barrier_wait (&otz_emu_self.blk->block_bar); }
+OTZ_DEV void otz_wave_sync() { pthread_barrier_wait (&otz_emu_self.blk->wave_bar[otz_emu_self.tid >> 6]); }
+OTZ_DEV void otz_emu_wave_sync() { pthread_barrier_wait (&otz_emu_self.blk->wave_bar[otz_emu_self.tid >> 6]); }
+OTZ_DEV void otz_backoff() { sched_yield (); }
+
+#endif
+
 OTZ_DEV u32 otz_tid() { return otz_emu_self.tid; }
 OTZ_DEV u32 otz_lane() { return otz_emu_self.tid & 63u; }
 OTZ_DEV u32 otz_wave() { return otz_emu_self.tid >> 6; }
 OTZ_DEV u32 otz_nthreads() { return otz_emu_self.blk->nthreads; }
-
-OTZ_DEV void otz_sync() { pthread_barrier_wait (&otz_emu_self.blk->block_bar); }
-OTZ_DEV void otz_wave_sync() { pthread_barrier_wait (&otz_emu_self.blk->wave_bar[otz_emu_self.tid >> 6]); }
-OTZ_DEV void otz_emu_wave_sync() { pthread_barrier_wait (&otz_emu_self.blk->wave_bar[otz_wave ()]); }
 
 OTZ_DEV u64 otz_ballot(bool p) {
 	otz_emu_block *b = otz_emu_self.blk;
@@ -77,6 +145,8 @@ OTZ_DEV u32 otz_shfl_up(u32 v, u32 d) {
 	return r;
 }
 OTZ_DEV u32 otz_shfl_xor(u32 v, u32 m) { return otz_shfl (v, otz_lane () ^ m); }
+OTZ_DEV u32 otz_readlane(u32 v, u32 src) { return otz_shfl (v, src); }
+OTZ_DEV u32 otz_uniform(u32 v) { return v; }
 
 OTZ_DEV void otz_lds_or(u32 *p, u32 v) { __atomic_fetch_or (p, v, __ATOMIC_RELAXED); }
 OTZ_DEV void otz_lds_min(u32 *p, u32 v) {
@@ -95,7 +165,6 @@ OTZ_DEV void otz_lds_store(u32 *p, u32 v) { __atomic_store_n (p, v, __ATOMIC_REL
 
 OTZ_DEV void otz_fence_release() { __atomic_thread_fence (__ATOMIC_RELEASE); }
 OTZ_DEV void otz_fence_acquire() { __atomic_thread_fence (__ATOMIC_ACQUIRE); }
-OTZ_DEV void otz_backoff() { sched_yield (); }
 OTZ_DEV void otz_set_priority_high() {}
 OTZ_DEV void otz_set_priority_normal() {}
 
@@ -109,6 +178,7 @@ OTZ_DEV u32 otz_brev(u32 v) {
 }
 OTZ_DEV u32 otz_ctz(u32 v) { return (u32)__builtin_ctz (v); }
 OTZ_DEV u32 otz_ctz64(u64 v) { return (u32)__builtin_ctzll (v); }
+OTZ_DEV u32 otz_clz64(u64 v) { return (u32)__builtin_clzll (v); }
 OTZ_DEV u32 otz_bfe(u32 v, u32 off, u32 width) { return (v >> (off & 31u)) & ((1u << (width & 31u)) - 1u); }
 OTZ_DEV u32 otz_alignbit(u32 hi, u32 lo, u32 sh) { return (u32) ((((u64)hi << 32) | lo) >> (sh & 31u)); }
 
