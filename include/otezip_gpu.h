@@ -166,8 +166,9 @@ int ozg_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
 int ozg_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
 int ozg_stream_sync(void *stream);
 
-/* Diagnostics only: d_buf = n x 16 uint64 device words which the inflate kernel fills with
- * per-phase shader-cycle counts for every entry of the following batches; NULL = off. */
+/* Diagnostics only: d_buf = n x 32 uint64 device words which the DEFLATE kernels fill with
+ * per-phase shader-cycle counts for every entry of the following batches (16 words of the
+ * apply kernel, then 16 of the index kernel); NULL = off. */
 void ozg_debug_set_profile_buffer(void *d_buf);
 
 /* Names of the kernels a profiler will show, for tooling. */

@@ -47,9 +47,23 @@ static_assert ((OTZ_IX_G & (OTZ_IX_G - 1u)) == 0, "power of two");
 #define OTZ_K1_NONE 0xFFFFFFFFu
 #define OTZ_X_CAP 2u // exit kind: token budget of the round used up (not an error; the block goes on)
 
+// Decode tables of the index kernel: 16-bit entries, 10-bit root for the literal/length code.
+// This kernel never needs a literal's value or a match's distance -- only how many bits a
+// token takes and how many bytes it yields -- so an entry is small, a long root fits, and
+// the second-level lookup (codes longer than the root) becomes rare.
+//   lit[]:  [3:0] code length (0: no code);  bit 4: length code, then [7:5] extra-bit count,
+//           [15:8] base length - 3;  else [7:5]: 0 literal, 1 end of block, 2 invalid symbol,
+//           3 link ([3:0] index width, [15:8] (sub-table start - root size) / 2)
+//   dist[]: code length + extra-bit count (1..28), 0: invalid symbol or no code;
+//           bit 15: link ([3:0] index width, [14:4] sub-table start - root size)
+#define OTZ_K1_LROOT 10u
+#define OTZ_K1_DROOT 8u
+#define OTZ_K1_LLUT 1344u // 1024 + 320 (zlib's ENOUGH for 286 symbols, root 10, 15 bits: 1332)
+#define OTZ_K1_DLUT 640u  // 256 + 384
+
 struct otz_k1_lds {
-	u32 lit_lut[OTZ_LIT_LUT];
-	u32 dist_lut[OTZ_DIST_LUT];
+	u16 lit[OTZ_K1_LLUT];
+	u16 dist[OTZ_K1_DLUT];
 	union {
 		u8 slots[64u * OTZ_K1_SLOT + 16u];
 		struct { // block prologue only
@@ -57,6 +71,7 @@ struct otz_k1_lds {
 			u32 cl_lut[128];
 			u8 ll[OTZ_IX_LENS];
 			u16 rank[OTZ_IX_LENS];
+			u8 subw[1u << OTZ_K1_LROOT]; // per root slot: index width of its sub-table (0: none)
 		} h;
 	};
 };
@@ -248,26 +263,61 @@ OTZ_DEV int otz_k1_parse_lengths(otz_k1_lds &L, u32 p, u64 avail, u32 n, u32 *bi
 	return 0;
 }
 
-// Both two-level decode tables from L.h.ll[0..hlit+hdist): the construction of
-// otz_build_tables (canonical code = first[len] + rank among the symbols of that length,
-// rank from ballots; root slots written by the symbol, sub-tables placed by a prefix sum
-// over the root slots), with one wavefront looping over chunks of 64 symbols / slots.
-// Returns false for an over-subscribed set or sub-tables that do not fit.
-OTZ_DEV bool otz_k1_build_tables(otz_k1_lds &L, u32 hlit, u32 hdist) {
-	constexpr u32 LRSZ = 1u << OTZ_LIT_ROOT, DRSZ = 1u << OTZ_DIST_ROOT;
+OTZ_DEV u32 otz_k1_mk_lit(u32 sym, u32 len) {
+	if (sym < 256u) {
+		return len;
+	}
+	if (sym == 256u) {
+		return len | (1u << 5);
+	}
+	if (sym > 285u) {
+		return len | (2u << 5); // ref deflate-dec.inc.c:794-797
+	}
+	const u32 k = sym - 257u;
+	u32 base, xb;
+	if (k < 8u) {
+		base = 3u + k;
+		xb = 0;
+	} else if (k == 28u) {
+		base = 258u;
+		xb = 0;
+	} else {
+		xb = (k >> 2) - 1u;
+		base = 3u + ((4u + (k & 3u)) << xb);
+	}
+	return len | 16u | (xb << 5) | ((base - 3u) << 8);
+}
+
+OTZ_DEV u32 otz_k1_mk_dist(u32 sym, u32 len) {
+	if (sym >= 30u) {
+		return 0; // the reference indexes past dist_base[] here (:766-774)
+	}
+	return len + (sym < 4u ? 0u : (sym >> 1) - 1u);
+}
+
+// Both decode tables from L.h.ll[0..hlit+hdist): canonical code = first[len] + rank among the
+// symbols of that length (ranks from ballots, no sorted list), root slots written by the
+// symbols themselves, sub-tables placed by a running sum over the root slots -- the
+// construction of otz_build_tables with one wavefront looping over chunks of 64.
+// Returns 0, OZG_ST_DATA for an over-subscribed set, or OTZ_IX_OVERFLOW when the sub-tables
+// do not fit these (smaller) tables.
+OTZ_DEV int otz_k1_build_tables(otz_k1_lds &L, u32 hlit, u32 hdist) {
 	const u32 lane = otz_lane ();
 	const u64 below = ((u64)1 << lane) - 1u;
-	for (u32 i = lane; i < OTZ_LIT_LUT; i += 64u) {
-		L.lit_lut[i] = OTZ_LUT_NONE;
+	for (u32 i = lane; i < OTZ_K1_LLUT / 2u; i += 64u) {
+		reinterpret_cast<u32 *> (L.lit)[i] = 0;
 	}
-	for (u32 i = lane; i < OTZ_DIST_LUT; i += 64u) {
-		L.dist_lut[i] = OTZ_LUT_NONE;
+	for (u32 i = lane; i < OTZ_K1_DLUT / 2u; i += 64u) {
+		reinterpret_cast<u32 *> (L.dist)[i] = 0;
 	}
-	bool ok = true;
+	int st = 0;
 	for (u32 tbl = 0; tbl < 2u; tbl++) {
 		const u32 nsym = tbl ? hdist : hlit, at0 = tbl ? hlit : 0u;
-		const u32 root = tbl ? OTZ_DIST_ROOT : OTZ_LIT_ROOT, rsz = tbl ? DRSZ : LRSZ, cap = tbl ? OTZ_DIST_LUT : OTZ_LIT_LUT;
-		u32 *const lut = tbl ? L.dist_lut : L.lit_lut;
+		const u32 root = tbl ? OTZ_K1_DROOT : OTZ_K1_LROOT, rsz = 1u << root, cap = tbl ? OTZ_K1_DLUT : OTZ_K1_LLUT;
+		u16 *const lut = tbl ? L.dist : L.lit;
+		for (u32 i = lane; i < rsz / 4u; i += 64u) {
+			reinterpret_cast<u32 *> (L.h.subw)[i] = 0;
+		}
 		// lane k (1..15) counts the symbols of length k; every symbol notes its rank
 		u32 cnt = 0;
 		for (u32 base = 0; base < nsym; base += 64u) {
@@ -297,22 +347,36 @@ OTZ_DEV bool otz_k1_build_tables(otz_k1_lds &L, u32 hlit, u32 hdist) {
 			}
 		}
 		// over-subscribed (ref: "left < 0") exactly when first[15] + count[15] > 2^15
-		ok = ok && otz_readlane (first + cnt, 15u) <= (1u << 15);
+		if (otz_readlane (first + cnt, 15u) > (1u << 15)) {
+			st = OZG_ST_DATA;
+		}
 		otz_wave_sync ();
-		// the symbols write their root slots, or claim a sub-table under their root slot
+		// short codes: the symbol writes every root slot that starts with its code
 		for (u32 base = 0; base < nsym; base += 64u) {
 			const u32 sym = base + lane;
 			const u32 l = sym < nsym ? L.h.ll[at0 + sym] : 0u;
 			const u32 f = otz_shfl (first, l);
-			if (l) {
+			if (l && l <= root) {
 				const u32 rr = otz_brev (f + L.h.rank[at0 + sym]) >> (32u - l);
-				if (l <= root) {
-					const u32 e = tbl ? otz_mk_dist_entry (sym, l) : otz_mk_lit_entry (sym, l);
-					for (u32 idx = rr; idx < rsz; idx += 1u << l) {
-						lut[idx] = e;
-					}
-				} else {
-					otz_lds_max (&lut[rr & (rsz - 1u)], (l - root) << 8);
+				const u16 e = (u16) (tbl ? otz_k1_mk_dist (sym, l) : otz_k1_mk_lit (sym, l));
+				for (u32 idx = rr; idx < rsz; idx += 1u << l) {
+					lut[idx] = e;
+				}
+			}
+		}
+		// long codes: their root slot needs a sub-table as wide as the longest of them.  Lengths
+		// in ascending order, plain stores: the LDS executes a wave's stores in order, the last wins.
+		for (u32 ll = root + 1u; ll <= 15u; ll++) {
+			if (otz_readlane (cnt, ll) == 0) {
+				continue;
+			}
+			for (u32 base = 0; base < nsym; base += 64u) {
+				const u32 sym = base + lane;
+				const u32 l = sym < nsym ? L.h.ll[at0 + sym] : 0u;
+				const u32 f = otz_shfl (first, l);
+				if (l == ll) {
+					const u32 rr = otz_brev (f + L.h.rank[at0 + sym]) >> (32u - l);
+					L.h.subw[rr & (rsz - 1u)] = (u8) (ll - root);
 				}
 			}
 		}
@@ -321,29 +385,30 @@ OTZ_DEV bool otz_k1_build_tables(otz_k1_lds &L, u32 hlit, u32 hdist) {
 		u32 total = 0;
 		for (u32 base = 0; base < rsz; base += 64u) {
 			const u32 slot = base + lane;
-			const u32 e = lut[slot];
-			const u32 sz = e && (e & 0xFFu) == 0 ? 1u << (e >> 8) : 0u; // claimed: (widest code - root) << 8
+			const u32 wd = L.h.subw[slot];
+			const u32 sz = wd ? 1u << wd : 0u;
 			const u32 incl = otz_wave_scan_incl (sz);
 			const u32 tot = otz_readlane (incl, 63u);
+			const u32 off = total + incl - sz; // relative to the end of the root table; even (every size is)
 			if (sz && total + tot <= cap - rsz) {
-				lut[slot] = OTZ_LUT_LINK | ((rsz + total + incl - sz) << 16) | ((e >> 8) << 8) | OTZ_LUT_NONE;
+				lut[slot] = (u16) (tbl ? 0x8000u | (off << 4) | wd : wd | (3u << 5) | ((off >> 1) << 8));
 			}
 			total += tot;
 		}
 		if (total > cap - rsz) {
-			ok = false;
+			st = st ? st : OTZ_IX_OVERFLOW;
 		}
 		otz_wave_sync ();
-		if (ok) {
+		if (st == 0) {
 			for (u32 base = 0; base < nsym; base += 64u) {
 				const u32 sym = base + lane;
 				const u32 l = sym < nsym ? L.h.ll[at0 + sym] : 0u;
 				const u32 f = otz_shfl (first, l);
 				if (l > root) {
 					const u32 rr = otz_brev (f + L.h.rank[at0 + sym]) >> (32u - l);
-					const u32 e = tbl ? otz_mk_dist_entry (sym, l) : otz_mk_lit_entry (sym, l);
+					const u16 e = (u16) (tbl ? otz_k1_mk_dist (sym, l) : otz_k1_mk_lit (sym, l));
 					const u32 link = lut[rr & (rsz - 1u)];
-					const u32 sb = (link >> 8) & 15u, sbase = (link >> 16) & 0x7FFFu;
+					const u32 sb = link & 15u, sbase = rsz + (tbl ? (link >> 4) & 0x7FFu : 2u * (link >> 8));
 					for (u32 idx = rr >> root; idx < (1u << sb); idx += 1u << (l - root)) {
 						lut[sbase + idx] = e;
 					}
@@ -352,7 +417,7 @@ OTZ_DEV bool otz_k1_build_tables(otz_k1_lds &L, u32 hlit, u32 hdist) {
 		}
 		otz_wave_sync ();
 	}
-	return ok;
+	return st;
 }
 
 // ------------------------------------------------------------------ the walks
@@ -361,87 +426,143 @@ struct otz_k1_path {
 	u32 exit;   // OTZ_X_MAKE (kind, slot-relative bit position): next token start, or the position after an EOB code
 	u32 n;      // tokens taken (each produced output)
 	u32 bytes;  // their output bytes
-	u32 nck;    // checkpoints written
-	u32 first;  // walk A: first token start at or behind the segment start (OTZ_K1_NONE: none); walk B: unused
-	u32 tstart; // start of the token examined last (the EOB code when the walk ended on one)
-	u32 merge;  // walk B: index of walk A's checkpoint it landed on, or OTZ_K1_NONE
+	u32 first;  // walk A: first token start at or behind the segment start (OTZ_K1_NONE: none)
+	u32 tstart; // where the walk stopped: start of the token it could not take (the EOB code when it ended on one)
+	u64 bm;     // walk A: bit (u - s) set for every token start u < s + 64
+	u32 mpos;   // walk B: position where it landed on walk A's path (OTZ_K1_NONE: never)
+	u32 mrow;   // walk B: ... which is walk A's checkpoint row mrow, or OTZ_K1_NONE when it is one of the early token starts
 };
 
-// One token at slot-relative bit u: one unaligned 8-byte LDS read covers its 48 bits at most.
-OTZ_DEV otz_tok otz_k1_decode(const otz_k1_lds &L, const u8 *slot, u32 u) {
+struct otz_k1_tok {
+	u32 nbits;  // stream bits of the whole token
+	u32 obytes; // output bytes: 1 for a literal, the match length
+	u32 kind;   // 0: literal or match, 1: end of block, 2: invalid
+};
+
+// One token at slot-relative bit u.  One unaligned 8-byte LDS read covers the 48 bits a token
+// can take; both table lookups are issued for every lane (a literal's distance lookup reads
+// some valid entry and is ignored), so the step is straight-line code but for the rare
+// second-level lookups.
+OTZ_DEV otz_k1_tok otz_k1_decode(const otz_k1_lds &L, const u8 *slot, u32 u) {
 	const u64 w = otz_ld64u (slot + (u >> 3)) >> (u & 7u);
-	return otz_decode_bits (L, (u32)w, (u32) (w >> 32));
+	const u32 lo = (u32)w, hi = (u32) (w >> 32);
+	u32 e = L.lit[lo & ((1u << OTZ_K1_LROOT) - 1u)];
+	if ((e & 0xF0u) == 0x60u) {
+		e = L.lit[(1u << OTZ_K1_LROOT) + 2u * (e >> 8) + otz_bfe (lo, OTZ_K1_LROOT, e & 15u)];
+	}
+	const u32 len = e & 15u;
+	const bool is_len = (e & 16u) != 0;
+	const u32 xb = otz_bfe (e, 5, 3); // length code: extra bits; else 0 literal, 1 end of block, 2 invalid
+	const u32 used = len + xb;
+	const u32 db = otz_alignbit (hi, lo, used);
+	u32 d = L.dist[db & ((1u << OTZ_K1_DROOT) - 1u)];
+	if (d & 0x8000u) {
+		d = L.dist[(1u << OTZ_K1_DROOT) + ((d >> 4) & 0x7FFu) + otz_bfe (db, OTZ_K1_DROOT, d & 15u)];
+	}
+	otz_k1_tok t;
+	t.nbits = is_len ? used + d : len;
+	t.obytes = is_len ? (e >> 8) + 3u + otz_bfe (lo >> len, 0, xb) : 1u;
+	t.kind = is_len ? (d ? 0u : 2u) : (e ? xb : 2u);
+	return t;
 }
 
-// Walk A (SPEC): from `start`; tokens before s are warm-up (neither counted nor noted).
-// Walk B (!SPEC): from the lane's true start; every token counts; stops on a checkpoint
-// position of walk A (ck_first = its first, rowsA/nckA the rest).
-// Straight-line loop body, one loop condition (cf. otz_walk in otz_inflate.h).
+// How a walk that stopped at slot-relative bit u ends: the exit word.
+OTZ_DEV u32 otz_k1_classify(const otz_k1_lds &L, const u8 *slot, u32 u, u32 e, u32 limit, bool capped) {
+	if (capped) {
+		return OTZ_X_MAKE (OTZ_X_CAP, u); // token budget used up
+	}
+	if (u >= e) {
+		return OTZ_X_MAKE (OTZ_X_NORMAL, u);
+	}
+	const otz_k1_tok t = otz_k1_decode (L, slot, u); // the token it stopped at
+	if (t.kind == 2u) {
+		return OTZ_X_MAKE (u >= limit ? OTZ_X_TRUNC : OTZ_X_INVALID, u);
+	}
+	if (u + t.nbits > limit) {
+		return OTZ_X_MAKE (OTZ_X_TRUNC, u);
+	}
+	return OTZ_X_MAKE (OTZ_X_EOB, u + t.nbits); // (kind 1: a token that neither breaks nor ends the input is taken)
+}
+
+// The walks.  All 64 lanes call; `run` selects the lanes that walk.
+//   SPEC (walk A): from `start`, OTZ_K1_WARM bits ahead of the segment: first a warm-up loop
+//     (tokens neither counted nor noted) up to the first token start at or behind s, then
+//     the main loop.  It notes a checkpoint (position, bytes so far) every OTZ_IX_G tokens in
+//     its column of `rows`, and the token starts of the segment's first 64 bits in a bitmap.
+//   !SPEC (walk B): from the lane's true start; stops as soon as it stands on walk A's path:
+//     on one of the early token starts (bmA) or on a checkpoint (rowsA / nckA).
+// The main loop counts tokens with ONE counter for the whole wavefront (every walking lane
+// takes one token per iteration), so the checkpoint cadence is a scalar branch, a row of
+// checkpoints is one coalesced store, and the body is straight-line code: a lane that has
+// stopped keeps decoding the token it stopped at and commits nothing.
 template <bool SPEC>
 OTZ_DEV otz_k1_path otz_k1_walk(const otz_k1_lds &L, const u8 *slot, bool run, u32 start, u32 s, u32 e, u32 limit,
-	otz_ix_item *rows, const otz_ix_item *rowsA, u32 ck_first, u32 nckA) {
-	const u32 lane = otz_lane ();
+	otz_ix_item *rows, const otz_ix_item *rowsA, u64 bmA, u32 nckA) {
 	otz_k1_path P;
-	u32 u = start, n = 0, bytes = 0, nck = 0, first = OTZ_K1_NONE, tstart = start;
-	u32 kind = OTZ_K_LIT, tend = start;
-	bool term = false, merged = false;
-	u32 c = 0, cpos = ck_first; // walk B: next checkpoint of walk A at or behind u
-	bool active = run;
-	while (otz_ballot (active) != 0) {
-		if (active) {
-			if (!SPEC) {
-				while (cpos < u) {
-					c++;
-					cpos = c < nckA ? rowsA[c * 64u + lane].bit : OTZ_K1_NONE;
-				}
-				merged = cpos == u;
-			}
-			if (!merged) {
-				const bool counted = !SPEC || u >= s;
-				if (counted && first == OTZ_K1_NONE) {
-					first = u;
-				}
-				if (counted && (n & (OTZ_IX_G - 1u)) == 0) {
-					otz_ix_item ck;
-					ck.bit = u;
-					ck.out = bytes;
-					rows[nck * 64u + lane] = ck;
-					nck++;
-				}
-				const otz_tok t = otz_k1_decode (L, slot, u);
-				kind = t.kind;
-				tstart = u;
-				tend = u + t.nbits;
-				term = kind >= OTZ_K_EOB || tend > limit;
-				if (!term) {
-					u = tend;
-					n += counted ? 1u : 0u;
-					bytes += counted ? (kind == OTZ_K_LIT ? 1u : t.val) : 0u;
-				}
-			}
-			active = !merged && !term && u < e && n < OTZ_K1_NCAP;
+	u32 u = run ? start : s; // (lanes that do not walk still execute the straight-line body: keep them inside the slot)
+	bool alive = run;
+	if (SPEC) {
+		while (alive && u < s) {
+			const otz_k1_tok t = otz_k1_decode (L, slot, u);
+			const u32 tend = u + t.nbits;
+			alive = t.kind == 0 && tend <= limit;
+			u = alive ? tend : u;
 		}
 	}
-	u32 xk = OTZ_X_NORMAL, xp = u;
-	if (term) {
-		if (kind == OTZ_K_BAD) {
-			xk = u >= limit ? OTZ_X_TRUNC : OTZ_X_INVALID;
-		} else if (tend > limit) {
-			xk = OTZ_X_TRUNC;
-		} else {
-			xk = OTZ_X_EOB;
-			xp = tend;
-		}
-	} else if (!merged && u < e) {
-		xk = OTZ_X_CAP; // n == OTZ_K1_NCAP
+	const u32 first = alive ? u : OTZ_K1_NONE;
+	u32 cnt = 0, bytes = 0;
+	u64 bm = 0;
+	bool merged = false;
+	u32 c = 1, cpos = OTZ_K1_NONE; // walk B: walk A's next checkpoint at or behind u (row 0 is its first token: bmA has it)
+	if (!SPEC) {
+		cpos = run && nckA > 1u ? rowsA[64u].bit : OTZ_K1_NONE;
 	}
-	P.exit = OTZ_X_MAKE (xk, xp);
-	P.n = n;
+	bool active = alive;
+	for (u32 n = 0; n < OTZ_K1_NCAP; n++) {
+		if (!SPEC) {
+			while (active && cpos < u) { // (rare: passed a checkpoint of walk A without landing on it)
+				c++;
+				cpos = c < nckA ? rowsA[c * 64u].bit : OTZ_K1_NONE;
+			}
+			bool hit = cpos == u;
+			if (n < 16u) { // the early token starts of walk A
+				const u32 rel = u - s;
+				hit = hit || (rel < 64u && ((bmA >> rel) & 1u) != 0);
+			}
+			merged = merged || (active && hit);
+			active = active && !merged;
+		}
+		if (SPEC && n < 8u) {
+			const u32 rel = u - s;
+			bm |= active && rel < 64u ? (u64)1 << rel : 0u;
+		}
+		if ((n & (OTZ_IX_G - 1u)) == 0) {
+			if (active) {
+				otz_ix_item k;
+				k.bit = u;
+				k.out = bytes;
+				rows[n * (64u / OTZ_IX_G)] = k; // row n / G of the lane's column
+			}
+		}
+		const otz_k1_tok t = otz_k1_decode (L, slot, u);
+		const u32 tend = u + t.nbits;
+		const bool adv = active && t.kind == 0 && tend <= limit;
+		u = adv ? tend : u;
+		cnt += adv ? 1u : 0u;
+		bytes += adv ? t.obytes : 0u;
+		active = adv && u < e;
+		if (otz_ballot (active) == 0) {
+			break;
+		}
+	}
+	P.exit = alive && !merged ? otz_k1_classify (L, slot, u, e, limit, active) : OTZ_X_MAKE (OTZ_X_INVALID, u);
+	P.n = cnt;
 	P.bytes = bytes;
-	P.nck = nck;
 	P.first = first;
-	P.tstart = tstart;
-	P.merge = merged ? c : OTZ_K1_NONE;
+	P.tstart = u;
+	P.bm = bm;
+	P.mpos = merged ? u : OTZ_K1_NONE;
+	P.mrow = merged && cpos == u ? c : OTZ_K1_NONE;
 	return P;
 }
 
@@ -453,8 +574,21 @@ OTZ_DEV otz_k1_path otz_k1_walk(const otz_k1_lds &L, const u8 *slot, bool run, u
 // entry's output address is 16-byte aligned; region/region_bytes: the entry's arena region
 // (region_bytes = 0: none could be carved).  head: the entry's index head.
 // Returns true when the index did not fit (head->status = OTZ_IX_OVERFLOW).
-OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap, bool out_aligned, u8 *region, u32 region_bytes, otz_ix_head *head) {
+// prof: optional 16 x u64 diagnostic cycle counters (0 header+lengths, 1 tables, 2 slot load, 3 walk A,
+// 4 fixpoint, 5 accept+items, 6 rounds, 7 fixpoint iterations, 8 re-walks, 9 blocks, 15 total)
+#define OTZ_K1_MARK(i) \
+	do { \
+		if (prof) { \
+			const u64 _t = otz_cycles (); \
+			pc[i] += _t - plast; \
+			plast = _t; \
+		} \
+	} while (0)
+OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap, bool out_aligned, u8 *region, u32 region_bytes, otz_ix_head *head, u64 *prof = nullptr) {
 	const u32 lane = otz_lane ();
+	u64 pc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+	u64 plast = otz_cycles ();
+	const u64 pstart = plast;
 	const u64 total_bits = (u64)n_in * 8u;
 	u64 abs_bit = 0;
 	u32 opos = 0;
@@ -474,8 +608,9 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 	} else if (region_bytes < OTZ_K1_TEMP_BYTES + 1024u) {
 		status = OTZ_IX_OVERFLOW;
 	}
-	const u32 rec_limit = region_bytes >= OTZ_K1_TEMP_BYTES ? region_bytes - OTZ_K1_TEMP_BYTES : 0u;
-	otz_ix_item *const rowsA = reinterpret_cast<otz_ix_item *> (region + rec_limit);
+	const u32 rec_limit = region_bytes >= OTZ_K1_TEMP_BYTES + 1024u ? region_bytes - OTZ_K1_TEMP_BYTES : 0u;
+	// checkpoint rows of the two walks, [row][lane]; this lane's column
+	otz_ix_item *const rowsA = reinterpret_cast<otz_ix_item *> (region + rec_limit) + lane;
 	otz_ix_item *const rowsB = rowsA + OTZ_K1_ROWS * 64u;
 
 	while (status == 0 && !ended) {
@@ -509,6 +644,7 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 		last_block = H.bfinal != 0;
 		last_btype = H.btype;
 		abs_bit += H.bits;
+		pc[9] += 1;
 		if (rec + 32u > rec_limit) {
 			status = OTZ_IX_OVERFLOW;
 			break;
@@ -584,10 +720,15 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 			}
 			reinterpret_cast<u32 *> (region + rec + 32u)[i] = w;
 		}
-		if (!otz_k1_build_tables (L, hlit, hdist)) {
-			status = OZG_ST_DATA;
-			break;
+		OTZ_K1_MARK (0);
+		{
+			const int st = otz_k1_build_tables (L, hlit, hdist);
+			if (st != 0) {
+				status = st;
+				break;
+			}
 		}
+		OTZ_K1_MARK (1);
 		otz_ix_item *const items = reinterpret_cast<otz_ix_item *> (region + rec + OTZ_IX_ITEMS_OFF);
 		const u32 items_cap = (rec_limit - rec - OTZ_IX_ITEMS_OFF) / 8u; // >= 1
 		const u64 block_bit = abs_bit;
@@ -622,19 +763,20 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 			const u32 s = OTZ_K1_WARM + phi, e = s + OTZ_K1_S;
 			const int64_t lb = (int64_t)total_bits - 8 * slot0; // the input ends at this slot-relative bit
 			const u32 limit = lb <= 0 ? 0u : lb > 0xFFFFFF ? 0xFFFFFFu : (u32)lb;
+			OTZ_K1_MARK (2);
+			pc[6] += 1;
 			// ---- walk A
 			const otz_k1_path A = otz_k1_walk<true> (L, slot, true, lane ? s - OTZ_K1_WARM : s, s, e, limit, rowsA, rowsA, 0, 0);
-			// ---- fixpoint over the true starts
+			const u32 nckA = (A.n + OTZ_IX_G - 1u) / OTZ_IX_G; // checkpoint rows in front of tokens walk A took
+			OTZ_K1_MARK (3);
+			// ---- fixpoint over the true starts.  A lane's true path: nB tokens of its own walk B
+			// (none when it starts on walk A's first token), then -- if it lands on walk A's path at
+			// mp -- walk A's tokens from its token number jm on (offA bytes precede that token there).
 			u32 t = lane == 0 ? s : OTZ_K1_NONE;
 			u32 exit_cur = A.exit;
-			bool onA = true;     // the true path is walk A's from checkpoint cm on
-			u32 cm = 0;          // (lane 0: walk A is the true path)
-			otz_k1_path B;
-			B.n = B.bytes = B.nck = 0;
-			B.exit = 0;
-			B.tstart = 0;
-			B.merge = OTZ_K1_NONE;
-			B.first = 0;
+			bool onA = true;
+			u32 mp = A.first, jm = 0, offA = 0; // (lane 0: walk A is the true path)
+			u32 nB = 0, bytesB = 0, tstartB = 0;
 			for (u32 it = 0; it < 64u; it++) {
 				const u32 prev = otz_shfl_up (exit_cur, 1);
 				// the left neighbour's exit is slot-relative to ITS slot: one segment further left
@@ -643,35 +785,60 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 				t = lane ? nt : t;
 				const bool rewalk = moved && nt != A.first;
 				const u32 old_exit = exit_cur;
+				pc[7] += 1;
 				if (otz_ballot (rewalk) != 0) {
-					const otz_k1_path W = otz_k1_walk<false> (L, slot, rewalk, nt, s, e, limit, rowsB, rowsA, A.first, A.nck);
+					pc[8] += 1;
+					const otz_k1_path W = otz_k1_walk<false> (L, slot, rewalk, nt, s, e, limit, rowsB, rowsA, A.bm, nckA);
+#ifdef OTZ_K1_STATS
 					if (rewalk) {
-						B = W;
-						onA = W.merge != OTZ_K1_NONE;
-						cm = onA ? W.merge : 0u;
+						fprintf (stderr, "rewalk it=%u lane=%u nt=%u Afirst=%d An=%u Wn=%u mpos=%d mrow=%d Aexit=%x Wexit=%x\n", it, lane, nt - s, (int) (A.first - s), A.n, W.n,
+							(int) (W.mpos == OTZ_K1_NONE ? -1 : (int) (W.mpos - s)), (int)W.mrow, A.exit, W.exit);
+					}
+#endif
+					// where on walk A's path did it land: count walk A's tokens up to there
+					const bool early = rewalk && W.mpos != OTZ_K1_NONE && W.mrow == OTZ_K1_NONE;
+					u32 x = A.first, j = 0, ob = 0;
+					while (early && x < W.mpos) {
+						const otz_k1_tok tk = otz_k1_decode (L, slot, x);
+						x += tk.nbits;
+						ob += tk.obytes;
+						j++;
+					}
+					if (rewalk) {
+						nB = W.n;
+						bytesB = W.bytes;
+						tstartB = W.tstart;
+						onA = W.mpos != OTZ_K1_NONE;
+						mp = W.mpos;
+						jm = early ? j : W.mrow * OTZ_IX_G;
+						offA = early ? ob : onA ? rowsA[W.mrow * 64u].out : 0u;
 						exit_cur = onA ? A.exit : W.exit;
 					}
 				}
 				if (moved && !rewalk) { // lands on walk A's first token: confirmed as it stands
-					B.n = B.bytes = B.nck = 0;
+					nB = bytesB = 0;
 					onA = true;
-					cm = 0;
+					mp = A.first;
+					jm = offA = 0;
 					exit_cur = A.exit;
 				}
 				if (otz_ballot (moved && exit_cur != old_exit) == 0) {
 					break;
 				}
 			}
+			OTZ_K1_MARK (4);
 			// ---- acceptance: lanes up to the first one whose path does not simply run on
 			const u64 termm = otz_ballot (OTZ_X_KIND (exit_cur) != OTZ_X_NORMAL);
 			const u32 F = termm ? otz_ctz64 (termm) : 63u; // last accepted lane
 			const bool acc = lane <= F;
-			// tokens of walk A before checkpoint cm are not on the true path
-			const u32 offA = onA && cm ? rowsA[cm * 64u + lane].out : 0u;
-			const u32 nA_items = onA ? (A.n + OTZ_IX_G - 1u) / OTZ_IX_G : 0u;
-			const u32 nB_items = (B.n + OTZ_IX_G - 1u) / OTZ_IX_G;
-			const u32 cnt = acc ? nB_items + (onA && nA_items > cm ? nA_items - cm : 0u) : 0u;
-			const u32 bytes = acc ? B.bytes + (onA ? A.bytes - offA : 0u) : 0u;
+			// items: walk B's checkpoint rows, then (on walk A's path, with tokens left there) one
+			// item at the landing point and walk A's rows behind it
+			const u32 nB_items = (nB + OTZ_IX_G - 1u) / OTZ_IX_G;
+			const bool tailA = onA && jm < A.n;
+			const u32 rA0 = jm / OTZ_IX_G + 1u; // first row of walk A behind the landing point
+			const u32 nA_rows = tailA && nckA > rA0 ? nckA - rA0 : 0u;
+			const u32 cnt = acc ? nB_items + (tailA ? 1u + nA_rows : 0u) : 0u;
+			const u32 bytes = acc ? bytesB + (onA ? A.bytes - offA : 0u) : 0u;
 			const u32 bincl = otz_wave_scan_incl (bytes);
 			const u32 cincl = otz_wave_scan_incl (cnt);
 			const u32 produced = otz_readlane (bincl, 63u), n_new = otz_readlane (cincl, 63u);
@@ -692,36 +859,43 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 				status = OTZ_IX_OVERFLOW;
 				break;
 			}
-			// ---- the accepted lanes' items, in stream order
+			// ---- the accepted lanes' items, in stream order.  Row by row: every load is
+			// independent of the others (and a row is one coalesced access).
 			{
-				// block-relative bit position of this lane's slot bit 0
-				const u32 bit0 = (u32) ((u64) (8 * slot0) - block_bit);
+				const u32 bit0 = (u32) ((u64) (8 * slot0) - block_bit); // block-relative bit position of this lane's slot bit 0
 				const u32 obase = opos - block_out + bincl - bytes;
 				otz_ix_item *dst = items + n_items + (cincl - cnt);
-				const u32 maxc = 2u * OTZ_K1_ROWS;
-				for (u32 k = 0; k < maxc; k++) {
-					if (otz_ballot (k < cnt) == 0) {
-						break;
-					}
-					if (k < cnt) {
-						otz_ix_item it;
-						if (k < nB_items) {
-							it = rowsB[k * 64u + lane];
-						} else {
-							it = rowsA[(cm + k - nB_items) * 64u + lane];
-							it.out = it.out - offA + B.bytes;
+				if (otz_ballot (acc && nB_items != 0) != 0) {
+					for (u32 r = 0; r < OTZ_K1_ROWS; r++) {
+						if (acc && r < nB_items) {
+							otz_ix_item it = rowsB[r * 64u];
+							it.bit += bit0;
+							it.out += obase;
+							dst[r] = it;
 						}
+					}
+				}
+				if (acc && tailA) {
+					otz_ix_item it;
+					it.bit = mp + bit0;
+					it.out = obase + bytesB;
+					dst[nB_items] = it;
+				}
+				for (u32 r = 1; r < OTZ_K1_ROWS; r++) {
+					if (acc && tailA && r >= rA0 && r < nckA) {
+						otz_ix_item it = rowsA[r * 64u];
 						it.bit += bit0;
-						it.out += obase;
-						dst[k] = it;
+						it.out += obase + bytesB - offA;
+						dst[nB_items + 1u + r - rA0] = it;
 					}
 				}
 			}
+			OTZ_K1_MARK (5);
 			n_items += n_new;
 			opos += produced;
 			// where the stream goes on (lane F's exit), and how the block ends
 			const u32 fexit = otz_readlane (exit_cur, F);
-			const u32 ftstart = otz_readlane (onA ? A.tstart : B.tstart, F);
+			const u32 ftstart = otz_readlane (onA ? A.tstart : tstartB, F);
 			const u64 fslot_bit = (u64) (8 * ((int64_t)rb + 64 * (int64_t)F - (int64_t) (OTZ_K1_WARM / 8u)));
 			abs_bit = fslot_bit + OTZ_X_POS (fexit);
 			if (fkind == OTZ_X_EOB) {
@@ -772,6 +946,12 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 		head->n_blocks = n_blocks;
 		head->first_block = 32u;
 		head->dbg[0] = head->dbg[1] = head->dbg[2] = 0;
+	}
+	if (prof && lane == 0) {
+		for (u32 i = 0; i < 10; i++) {
+			prof[i] = pc[i];
+		}
+		prof[15] = otz_cycles () - pstart;
 	}
 	return status == OTZ_IX_OVERFLOW;
 }

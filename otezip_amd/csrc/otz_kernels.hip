@@ -68,9 +68,9 @@ otz_plan_kernel(const ozg_entry *entries, u32 n, u64 src_len, u64 dst_len, u64 a
 // One wavefront per entry, no workgroup barrier anywhere: the number of entries in flight
 // per CU is set by LDS (12 KB each) and registers alone.
 extern "C" __global__ void __launch_bounds__ (64)
-__attribute__ ((amdgpu_waves_per_eu (3, 8)))
+__attribute__ ((amdgpu_waves_per_eu (4, 8)))
 otz_index_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, u32 n, u64 src_len, u64 dst_len, ozg_limits lim, u8 *arena, const otz_region *regions, otz_ix_head *heads,
-	u32 *ovf) {
+	u32 *ovf, u64 *prof) {
 	extern __shared__ __attribute__ ((aligned (16))) u8 otz_smem[];
 	const u32 i = blockIdx.x;
 	if (i >= n) {
@@ -82,7 +82,7 @@ otz_index_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, u32 n, u64 sr
 		return;
 	}
 	const otz_region r = regions[i];
-	if (otz_run_index (L, src, dst, e, lim, &heads[i], arena + r.off, r.bytes) && otz_lane () == 0) {
+	if (otz_run_index (L, src, dst, e, lim, &heads[i], arena + r.off, r.bytes, prof ? prof + 32ull * i + 16u : nullptr) && otz_lane () == 0) {
 		ovf[1u + atomicAdd (&ovf[0], 1u)] = i; // ovf[0]: count, then the entries
 	}
 }
@@ -120,7 +120,7 @@ otz_apply_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *r
 		otz_fail (&results[i], OZG_ST_INTERNAL);
 		return;
 	}
-	otz_run_apply (L, src, dst, e, &results[i], lim, &heads[i], arena + regions[i].off, prof ? prof + 16ull * i : nullptr);
+	otz_run_apply (L, src, dst, e, &results[i], lim, &heads[i], arena + regions[i].off, prof ? prof + 32ull * i : nullptr);
 }
 
 extern "C" __global__ void __launch_bounds__ (256)
@@ -449,7 +449,7 @@ int ozg_decode_batch_device_ex(const void *d_src, uint64_t src_len, void *d_dst,
 			(u64)g_ws.arena_cap, g_ws.cursor, g_ws.regions, g_ws.heads);
 		OZG_HIP (hipGetLastError ());
 		hipLaunchKernelGGL (otz_index_kernel, dim3 (n), dim3 (64), sizeof (otz_k1_lds), s, (const u8 *)d_src, (u8 *)d_dst, d_entries, n,
-			(u64)src_len, (u64)dst_len, g_limits, g_ws.arena, g_ws.regions, g_ws.heads, g_ws.ovf);
+			(u64)src_len, (u64)dst_len, g_limits, g_ws.arena, g_ws.regions, g_ws.heads, g_ws.ovf, g_prof);
 		OZG_HIP (hipGetLastError ());
 		hipLaunchKernelGGL (otz_apply_kernel, dim3 (n), dim3 (OTZ_NT), sizeof (otz_inflate_lds), s, (const u8 *)d_src, (u8 *)d_dst,
 			d_entries, d_results, n, (u64)src_len, (u64)dst_len, g_limits, (const u8 *)g_ws.arena, g_ws.regions, g_ws.heads, g_prof);
@@ -680,8 +680,8 @@ int ozg_stream_sync(void *stream) {
 	return OZG_OK;
 }
 
-/* Diagnostics only: d_buf = n x 16 uint64 device words that the inflate kernel fills with
- * per-phase cycle counts of every entry (NULL switches it off). */
+/* Diagnostics only: d_buf = n x 32 uint64 device words: per entry 16 phase cycle counters of the
+ * apply kernel, then 16 of the index kernel (NULL switches it off). */
 void ozg_debug_set_profile_buffer(void *d_buf) { g_prof = (u64 *)d_buf; }
 
 const char *ozg_kernel_name_inflate(void) { return "otz_apply_kernel"; }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: per-phase shader-cycle breakdown of otz_inflate_kernel (work-item 0's view of
+"""Diagnostic: per-phase shader-cycle breakdown of otz_apply_kernel (work-item 0's view of
 each workgroup), via ozg_debug_set_profile_buffer.  Not part of the timed benchmark."""
 import os
 import sys
@@ -28,7 +28,7 @@ def main():
     d_dst = torch.empty(dst_len + 64, dtype=torch.uint8, device=dev)
     d_ent = torch.frombuffer(bytearray(bytes(et)), dtype=torch.uint8).to(dev)
     d_res = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
-    d_prof = torch.zeros(n * 16, dtype=torch.int64, device=dev)
+    d_prof = torch.zeros(n * 32, dtype=torch.int64, device=dev)
     s = torch.cuda.current_stream()
 
     def run():
@@ -46,7 +46,9 @@ def main():
     run()
     torch.cuda.synchronize()
     L.ozg_debug_set_profile_buffer(None)
-    p = d_prof.cpu().numpy().reshape(n, 16).astype(np.float64)
+    pall = d_prof.cpu().numpy().reshape(n, 32).astype(np.float64)
+    p = pall[:, :16]
+    k1 = pall[:, 16:]
     res = np.frombuffer(d_res.cpu().numpy().tobytes(), dtype=np.int32).reshape(n, 4)
     print("status ok:", int((res[:, 0] == 1).sum()), "/", n)
     tot = p[:, 15].mean()
@@ -58,6 +60,16 @@ def main():
             print("%-9s %10.1f" % (name, m))
         else:
             print("%-9s %10.0f cyc  %5.1f%%" % (name, m, 100 * m / tot))
+    print("---- otz_index_kernel (one wavefront per entry)")
+    K1 = ["hdr+lens", "tables", "slots", "walkA", "fixpoint", "accept", "rounds#", "fix_iters#", "rewalks#", "blocks#"]
+    tot1 = k1[:, 15].mean()
+    for i, name in enumerate(K1):
+        m = k1[:, i].mean()
+        if name.endswith("#"):
+            print("%-10s %10.1f" % (name, m))
+        else:
+            print("%-10s %10.0f cyc  %5.1f%%" % (name, m, 100 * m / tot1))
+    print("%-10s %10.0f cyc" % ("total", tot1))
     oz.shutdown()
 
 
