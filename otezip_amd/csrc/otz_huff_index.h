@@ -36,6 +36,7 @@
 #define OTZ_K1_S 512u     // segment bits per lane per round
 #define OTZ_K1_WARM 128u  // head start of walk A (bits)
 #define OTZ_K1_SLOT 92u   // slot bytes per lane: WARM/8 before + S/8 + 12 behind; 23 dwords (odd: no bank conflicts)
+                          // (a walk prefetches up to three words past its slot: the next lane's, never used)
 #define OTZ_K1_NCAP (OTZ_K1_ROWS * OTZ_IX_G) // tokens a walk may take per round
 #define OTZ_K1_HDR_WORDS 264u // staged bytes for a block header: 17 + 57 + 318 x 14 bits < 1056 bytes
 
@@ -65,7 +66,7 @@ struct otz_k1_lds {
 	u16 lit[OTZ_K1_LLUT];
 	u16 dist[OTZ_K1_DLUT];
 	union {
-		u8 slots[64u * OTZ_K1_SLOT + 16u];
+		u8 slots[64u * OTZ_K1_SLOT + 32u];
 		struct { // block prologue only
 			u32 hdr_w[OTZ_K1_HDR_WORDS + 4u];
 			u32 cl_lut[128];
@@ -439,13 +440,10 @@ struct otz_k1_tok {
 	u32 kind;   // 0: literal or match, 1: end of block, 2: invalid
 };
 
-// One token at slot-relative bit u.  One unaligned 8-byte LDS read covers the 48 bits a token
-// can take; both table lookups are issued for every lane (a literal's distance lookup reads
-// some valid entry and is ignored), so the step is straight-line code but for the rare
-// second-level lookups.
-OTZ_DEV otz_k1_tok otz_k1_decode(const otz_k1_lds &L, const u8 *slot, u32 u) {
-	const u64 w = otz_ld64u (slot + (u >> 3)) >> (u & 7u);
-	const u32 lo = (u32)w, hi = (u32) (w >> 32);
+// One token whose bits start at bit 0 of (hi:lo); both table lookups are issued for every lane
+// (a literal's distance lookup reads some valid entry and is ignored), so the step is
+// straight-line code but for the rare second-level lookups.
+OTZ_DEV otz_k1_tok otz_k1_decode_bits(const otz_k1_lds &L, u32 lo, u32 hi) {
 	u32 e = L.lit[lo & ((1u << OTZ_K1_LROOT) - 1u)];
 	if ((e & 0xF0u) == 0x60u) {
 		e = L.lit[(1u << OTZ_K1_LROOT) + 2u * (e >> 8) + otz_bfe (lo, OTZ_K1_LROOT, e & 15u)];
@@ -464,6 +462,52 @@ OTZ_DEV otz_k1_tok otz_k1_decode(const otz_k1_lds &L, const u8 *slot, u32 u) {
 	t.obytes = is_len ? (e >> 8) + 3u + otz_bfe (lo >> len, 0, xb) : 1u;
 	t.kind = is_len ? (d ? 0u : 2u) : (e ? xb : 2u);
 	return t;
+}
+
+// Stateless form: three dword-aligned slot words and a funnel shift (a byte-unaligned 8-byte
+// LDS read costs 5x the LDS time).
+OTZ_DEV otz_k1_tok otz_k1_decode(const otz_k1_lds &L, const u8 *slot, u32 u) {
+	const u32 *wp = reinterpret_cast<const u32 *> (slot) + (u >> 5);
+	const u64 w01 = otz_ld64u (wp);
+	const u32 w2 = wp[2];
+	return otz_k1_decode_bits (L, otz_alignbit ((u32) (w01 >> 32), (u32)w01, u), otz_alignbit (w2, (u32) (w01 >> 32), u));
+}
+
+// A walk keeps three slot words (96 stream bits from the word holding its position) in
+// registers and asks for the next two BEFORE it decodes: they arrive while the table lookups
+// are in flight, and the window then slides by 0-2 words to the next token -- so a step waits
+// for the two table lookups only, not for the stream.  (A token is at most 48 bits.)
+struct otz_k1_win {
+	u32 w0, w1, w2;
+	u32 a; // slot word index of w0; the walk's position lies in that word
+};
+OTZ_DEV void otz_k1_win_init(otz_k1_win &W, const u8 *slot, u32 u) {
+	const u32 *sw = reinterpret_cast<const u32 *> (slot);
+	W.a = u >> 5;
+	W.w0 = sw[W.a];
+	W.w1 = sw[W.a + 1u];
+	W.w2 = sw[W.a + 2u];
+}
+// decode at u (which lies in word W.a); then slide the window to `nu` (>= u, < u + 49) with
+// otz_k1_win_slide -- in between the caller decides whether the lane takes the token at all
+struct otz_k1_pre {
+	u32 p0, p1;
+};
+OTZ_DEV otz_k1_tok otz_k1_win_decode(const otz_k1_lds &L, const u8 *slot, const otz_k1_win &W, u32 u, otz_k1_pre &P) {
+	const u64 p01 = otz_ld64u (reinterpret_cast<const u32 *> (slot) + W.a + 3u); // (4-byte aligned; beyond the slot: the next lane's, unused)
+	P.p0 = (u32)p01;
+	P.p1 = (u32) (p01 >> 32);
+	return otz_k1_decode_bits (L, otz_alignbit (W.w1, W.w0, u), otz_alignbit (W.w2, W.w1, u));
+}
+OTZ_DEV void otz_k1_win_slide(otz_k1_win &W, const otz_k1_pre &P, u32 nu) {
+	const u32 na = nu >> 5, d = na - W.a;
+	const u32 n0 = d == 0 ? W.w0 : d == 1u ? W.w1 : W.w2;
+	const u32 n1 = d == 0 ? W.w1 : d == 1u ? W.w2 : P.p0;
+	const u32 n2 = d == 0 ? W.w2 : d == 1u ? P.p0 : P.p1;
+	W.w0 = n0;
+	W.w1 = n1;
+	W.w2 = n2;
+	W.a = na;
 }
 
 // How a walk that stopped at slot-relative bit u ends: the exit word.
@@ -501,12 +545,16 @@ OTZ_DEV otz_k1_path otz_k1_walk(const otz_k1_lds &L, const u8 *slot, bool run, u
 	otz_k1_path P;
 	u32 u = run ? start : s; // (lanes that do not walk still execute the straight-line body: keep them inside the slot)
 	bool alive = run;
+	otz_k1_win W;
+	otz_k1_pre PF;
+	otz_k1_win_init (W, slot, u);
 	if (SPEC) {
 		while (alive && u < s) {
-			const otz_k1_tok t = otz_k1_decode (L, slot, u);
+			const otz_k1_tok t = otz_k1_win_decode (L, slot, W, u, PF);
 			const u32 tend = u + t.nbits;
 			alive = t.kind == 0 && tend <= limit;
 			u = alive ? tend : u;
+			otz_k1_win_slide (W, PF, u);
 		}
 	}
 	const u32 first = alive ? u : OTZ_K1_NONE;
@@ -544,10 +592,11 @@ OTZ_DEV otz_k1_path otz_k1_walk(const otz_k1_lds &L, const u8 *slot, bool run, u
 				rows[n * (64u / OTZ_IX_G)] = k; // row n / G of the lane's column
 			}
 		}
-		const otz_k1_tok t = otz_k1_decode (L, slot, u);
+		const otz_k1_tok t = otz_k1_win_decode (L, slot, W, u, PF);
 		const u32 tend = u + t.nbits;
 		const bool adv = active && t.kind == 0 && tend <= limit;
 		u = adv ? tend : u;
+		otz_k1_win_slide (W, PF, u);
 		cnt += adv ? 1u : 0u;
 		bytes += adv ? t.obytes : 0u;
 		active = adv && u < e;
@@ -777,6 +826,7 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 			bool onA = true;
 			u32 mp = A.first, jm = 0, offA = 0; // (lane 0: walk A is the true path)
 			u32 nB = 0, bytesB = 0, tstartB = 0;
+#pragma unroll 1
 			for (u32 it = 0; it < 64u; it++) {
 				const u32 prev = otz_shfl_up (exit_cur, 1);
 				// the left neighbour's exit is slot-relative to ITS slot: one segment further left
@@ -866,6 +916,7 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 				const u32 obase = opos - block_out + bincl - bytes;
 				otz_ix_item *dst = items + n_items + (cincl - cnt);
 				if (otz_ballot (acc && nB_items != 0) != 0) {
+#pragma unroll 2
 					for (u32 r = 0; r < OTZ_K1_ROWS; r++) {
 						if (acc && r < nB_items) {
 							otz_ix_item it = rowsB[r * 64u];
@@ -881,6 +932,7 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 					it.out = obase + bytesB;
 					dst[nB_items] = it;
 				}
+#pragma unroll 4
 				for (u32 r = 1; r < OTZ_K1_ROWS; r++) {
 					if (acc && tailA && r >= rA0 && r < nckA) {
 						otz_ix_item it = rowsA[r * 64u];

@@ -25,6 +25,7 @@
 #include <mutex>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include "otz_dispatch.h"
 #include "otz_deflate_enc.h"
@@ -36,6 +37,10 @@ static_assert (sizeof (otz_inflate_lds) <= 80 * 1024, "two inflate workgroups pe
 
 static_assert (OTZ_NT * OTZ_S_BITS / 8 + 512 <= OTZ_STAGE_BYTES, "stage must cover one round of input");
 static_assert (sizeof (otz_ix_head) == 32 && sizeof (otz_ix_block) == 32 && sizeof (otz_ix_item) == 8, "index layout");
+
+#ifndef OTZ_K1_WPE
+#define OTZ_K1_WPE 4
+#endif
 
 struct otz_region {
 	u64 off;   // byte offset into the index arena
@@ -68,7 +73,7 @@ otz_plan_kernel(const ozg_entry *entries, u32 n, u64 src_len, u64 dst_len, u64 a
 // One wavefront per entry, no workgroup barrier anywhere: the number of entries in flight
 // per CU is set by LDS (12 KB each) and registers alone.
 extern "C" __global__ void __launch_bounds__ (64)
-__attribute__ ((amdgpu_waves_per_eu (4, 8)))
+__attribute__ ((amdgpu_waves_per_eu (OTZ_K1_WPE, 8)))
 otz_index_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, u32 n, u64 src_len, u64 dst_len, ozg_limits lim, u8 *arena, const otz_region *regions, otz_ix_head *heads,
 	u32 *ovf, u64 *prof) {
 	extern __shared__ __attribute__ ((aligned (16))) u8 otz_smem[];
@@ -448,9 +453,12 @@ int ozg_decode_batch_device_ex(const void *d_src, uint64_t src_len, void *d_dst,
 		hipLaunchKernelGGL (otz_plan_kernel, dim3 ((n + 255u) / 256u), dim3 (256), 0, s, d_entries, n, (u64)src_len, (u64)dst_len,
 			(u64)g_ws.arena_cap, g_ws.cursor, g_ws.regions, g_ws.heads);
 		OZG_HIP (hipGetLastError ());
+		const char *dbg_skip = getenv ("OTZ_DEBUG_SKIP"); // diagnostics: "index" / "apply" leaves that launch out
+		if (!(dbg_skip && strstr (dbg_skip, "index")))
 		hipLaunchKernelGGL (otz_index_kernel, dim3 (n), dim3 (64), sizeof (otz_k1_lds), s, (const u8 *)d_src, (u8 *)d_dst, d_entries, n,
 			(u64)src_len, (u64)dst_len, g_limits, g_ws.arena, g_ws.regions, g_ws.heads, g_ws.ovf, g_prof);
 		OZG_HIP (hipGetLastError ());
+		if (!(dbg_skip && strstr (dbg_skip, "apply")))
 		hipLaunchKernelGGL (otz_apply_kernel, dim3 (n), dim3 (OTZ_NT), sizeof (otz_inflate_lds), s, (const u8 *)d_src, (u8 *)d_dst,
 			d_entries, d_results, n, (u64)src_len, (u64)dst_len, g_limits, (const u8 *)g_ws.arena, g_ws.regions, g_ws.heads, g_prof);
 		OZG_HIP (hipGetLastError ());

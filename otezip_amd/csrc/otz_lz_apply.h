@@ -17,6 +17,235 @@
 
 #define OTZ_K1_ST_NEED_OUT_HEAD (-100)
 
+// ---------------------------------------------------------------- placement
+//
+// Lane j decodes item j: at most OTZ_IX_G tokens from stage bit s_bit up to e_bit, first
+// output byte at absolute position o_abs.  Literals go to their final ring bytes (and are
+// marked final); a match is parked in the first three bytes of its own destination (23 bits:
+// distance-1 : 15, length-3 : 8 -- a match is at least three bytes long) and its destination
+// is noted.  The loop is unrolled: every lane runs the same OTZ_IX_G steps, three aligned stage
+// words and the two table lookups each, no loop-carried window.
+// Afterwards the destinations of all matches of the round are written, in stream order, to
+// `list` (round-relative, u16): a prefix sum over the lanes' match counts gives every lane its
+// slice.  Returns the number of matches of the round.  All OTZ_NT work-items.
+static_assert (OTZ_IX_G == 8u, "eight 16-bit destinations are packed into two 64-bit registers");
+static_assert (OTZ_NT * OTZ_IX_G * 2u <= OTZ_STAGE_BYTES, "the match list of a round fits the stage buffer");
+OTZ_DEV u32 otz_place_items(otz_inflate_lds &L, bool active, u32 s_bit, u32 e_bit, u32 o_abs, u32 round_base, u16 *list) {
+	u32 pos = s_bit;
+	u32 rel = active ? o_abs - round_base : 0u; // round-relative output position
+	u32 ri = OTZ_RIDX (active ? o_abs : round_base);
+	u32 curw = rel >> 5, finm = 0;
+	u32 nm = 0;
+	u64 pk_lo = 0, pk_hi = 0;
+	bool bad = false, too_far = false;
+	otz_win W;
+	otz_win_init (W, L, pos);
+#pragma unroll
+	for (u32 i = 0; i < OTZ_IX_G; i++) {
+		const bool act = active && pos < e_bit && !bad;
+		// (three stage words in registers, the next two asked for before the lookups: otz_win)
+		const u32 p0 = L.stage_w[W.a + 3u], p1 = L.stage_w[W.a + 4u];
+		const otz_tok t = otz_decode_bits (L, otz_alignbit (W.w1, W.w0, pos), otz_alignbit (W.w2, W.w1, pos));
+		const bool lit = t.kind == OTZ_K_LIT, mat = t.kind == OTZ_K_LEN;
+		// (the index kernel validated the chain: anything else here is an internal error)
+		bad = bad || (act && !lit && !mat);
+		// ref reads window bytes nobody wrote (:524): no parity, fail cleanly
+		too_far = too_far || (act && mat && t.dist > round_base + rel);
+		const bool put = act && (lit || mat) && !too_far;
+		const u32 wd = rel >> 5;
+		if (put && wd != curw) {
+			otz_lds_or (&L.fin[curw], finm);
+			curw = wd;
+			finm = 0;
+		}
+		const u32 d = (t.dist - 1u) | ((t.val - 3u) << 15); // the parked match
+		if (put) {
+			L.ring[ri] = (u8) (lit ? t.val : d);
+			if (mat) {
+				L.ring[OTZ_RWRAP (ri + 1u)] = (u8) (d >> 8);
+				L.ring[OTZ_RWRAP (ri + 2u)] = (u8) (d >> 16);
+			}
+		}
+		finm |= put && lit ? 1u << (rel & 31u) : 0u;
+		{
+			const u64 v = (u64)rel << (16u * (nm & 3u));
+			const bool m = put && mat;
+			pk_lo |= m && nm < 4u ? v : 0u;
+			pk_hi |= m && nm >= 4u ? v : 0u;
+			nm += m ? 1u : 0u;
+		}
+		const u32 adv = lit ? 1u : t.val;
+		rel += put ? adv : 0u;
+		ri = put ? OTZ_RWRAP (ri + adv) : ri;
+		pos += put ? t.nbits : 0u;
+		{
+			const u32 na = pos >> 5, dd = na - W.a; // a token is at most 48 bits: 0-2 words further
+			const u32 n0 = dd == 0 ? W.w0 : dd == 1u ? W.w1 : W.w2;
+			const u32 n1 = dd == 0 ? W.w1 : dd == 1u ? W.w2 : p0;
+			const u32 n2 = dd == 0 ? W.w2 : dd == 1u ? p0 : p1;
+			W.w0 = n0;
+			W.w1 = n1;
+			W.w2 = n2;
+			W.a = na;
+		}
+	}
+	if (finm) {
+		otz_lds_or (&L.fin[curw], finm);
+	}
+	if (too_far) {
+		otz_set_status (L, OZG_ST_DATA);
+	} else if (bad || (active && pos != e_bit)) {
+		L.dbg[0] = 2; // the index and the stream disagree
+		L.dbg[1] = otz_tid ();
+		L.dbg[2] = pos;
+		L.dbg[3] = e_bit;
+		otz_set_status (L, OZG_ST_INTERNAL);
+	}
+	u32 total;
+	const u32 incl = otz_block_scan_incl (nm, L.scan, &total); // (two barriers: every stage read is done)
+	const u32 at = incl - nm;
+#pragma unroll
+	for (u32 q = 0; q < OTZ_IX_G; q++) {
+		if (q < nm) {
+			list[at + q] = (u16) ((q < 4u ? pk_lo : pk_hi) >> (16u * (q & 3u)));
+		}
+	}
+	return total;
+}
+
+// ---------------------------------------------------------------- LZ77 resolution
+//
+// The copies, in stream order: lane j takes matches j, j + OTZ_NT, ... of the list, one after
+// the other, and fetches the next as soon as one is done (no lane waits for the slowest of a
+// batch).  OTZ_NT consecutive matches span a few KB of output, so most sources lie in
+// stretches that are already final; the others wait for exactly the bytes they need: each
+// step copies up to 16 bytes once the per-byte final bits of THOSE source bytes are set (two
+// bitmap words and the 16 source bytes in one LDS round trip), then sets the bits of what it
+// wrote.  The earliest unresolved match of the round is some lane's current one and never
+// waits, so the loop cannot stall; it is closed by ballots (a convergent exit keeps the waiting lanes and the
+// lanes they wait for in the same loop -- see otz_resolve in otz_inflate.h).
+// An overlapping match (distance < 16) copies one period, then two, four, ...
+OTZ_DEV void otz_resolve_list(otz_inflate_lds &L, const otz_job &J, u32 round_base, const u16 *list, u32 n_matches) {
+	constexpr u32 FIN_WORDS = OTZ_RMAX / 32u;
+	const u32 rb = OTZ_RIDX (round_base);
+	u32 m = otz_tid (); // this lane's next match
+	u32 pend = 0, pdist = 1, o = 0, ri = 0, si = 0;
+	u32 spins = 0;
+	for (;;) {
+		OTZ_COUNT (L, J, OTZ_P_B_ITERS, 1);
+		if (pend == 0 && m < n_matches) {
+			// ---- next match of this lane: its parked descriptor
+			const u32 at = list[m];
+			const u32 ai = OTZ_RWRAP (rb + at);
+			u32 cd;
+			if (ai + 3u > OTZ_RING) {
+				cd = (u32)L.ring[ai] | ((u32)L.ring[OTZ_RWRAP (ai + 1u)] << 8) | ((u32)L.ring[OTZ_RWRAP (ai + 2u)] << 16);
+			} else {
+				const u64 dw = otz_ld64u (&L.ring[ai & ~3u]); // (may read past the ring's end: still inside the LDS block)
+				cd = otz_alignbyte ((u32) (dw >> 32), (u32)dw, ai) & 0xFFFFFFu;
+			}
+			pdist = (cd & 0x7FFFu) + 1u;
+			pend = (cd >> 15) + 3u;
+			o = at;
+			ri = ai;
+			si = ai >= pdist ? ai - pdist : ai + OTZ_RING - pdist;
+			m += OTZ_NT;
+		}
+		// ---- one step: up to 16 bytes that neither overlap their own source nor cross the ring's end
+		u32 n = pend < 16u ? pend : 16u;
+		n = n < pdist ? n : pdist;
+		n = n < OTZ_RING - ri ? n : OTZ_RING - ri;
+		n = n < OTZ_RING - si ? n : OTZ_RING - si;
+		// their source, round-relative [a, b); what lies before the round is final
+		const int so = (int)o - (int)pdist;
+		const u32 a = so < 0 ? 0u : (u32)so;
+		const int be = so + (int)n;
+		const u32 b = be < 0 ? 0u : (u32)be;
+		const u32 w0 = a >> 5 < FIN_WORDS - 1u ? a >> 5 : FIN_WORDS - 2u; // (b - a <= 16 bits: words w0, w0 + 1 hold them)
+		const u64 have = otz_ld64u (&L.fin[w0]);
+		otz_order_loads (); // "flag, then data": the source bytes are read after the bits that declare them final
+		const u64 need = b > a ? (((u64)1 << (b - a)) - 1u) << (a - 32u * w0) : 0u;
+		const bool go = pend != 0 && (have & need) == need;
+		if (go) {
+			// the source bytes: dword-aligned reads, then a byte funnel shift (reads past the bytes
+			// used, and past the ring's end, land in the LDS block and are ignored)
+			const u32 *sp = reinterpret_cast<const u32 *> (&L.ring[si & ~3u]);
+			const u64 s01 = otz_ld64u (sp);
+			const u32 s2 = sp[2];
+			const u64 lo = otz_alignbyte ((u32) (s01 >> 32), (u32)s01, si) | ((u64)otz_alignbyte (s2, (u32) (s01 >> 32), si) << 32);
+			u64 hi = 0;
+			if (n > 8u) {
+				const u64 s34 = otz_ld64u (sp + 3);
+				hi = otz_alignbyte ((u32)s34, s2, si) | ((u64)otz_alignbyte ((u32) (s34 >> 32), (u32)s34, si) << 32);
+			}
+			// an unaligned 2-byte store is cheap, an unaligned 4-byte store costs three of them
+			u8 *dst = &L.ring[ri];
+			u64 v = lo;
+			if (n & 16u) {
+				otz_st64u (dst, lo);
+				otz_st64u (dst + 8, hi);
+			} else {
+				if (n & 8u) {
+					otz_st64u (dst, lo);
+					v = hi;
+					dst += 8;
+				}
+				if (n & 4u) {
+					otz_st16u (dst, (u16)v);
+					otz_st16u (dst + 2, (u16) (v >> 16));
+					v >>= 32;
+					dst += 4;
+				}
+				if (n & 2u) {
+					otz_st16u (dst, (u16)v);
+					v >>= 16;
+					dst += 2;
+				}
+				if (n & 1u) {
+					*dst = (u8)v;
+				}
+			}
+			otz_order_stores ();
+			const u64 mask = (((u64)1 << n) - 1u) << (o & 31u);
+			otz_lds_or (&L.fin[o >> 5], (u32)mask);
+			if ((u32) (mask >> 32)) {
+				otz_lds_or (&L.fin[(o >> 5) + 1u], (u32) (mask >> 32));
+			}
+			o += n;
+			ri = OTZ_RWRAP (ri + n);
+			pend -= n;
+			// a whole period written: same source, twice the reach; otherwise the source slides along
+			const bool dbl = n == pdist && pdist < 16u;
+			si = dbl ? si : OTZ_RWRAP (si + n);
+			pdist += dbl ? n : 0u;
+		}
+		if (J.prof) { // diagnostics: lanes that copied / lanes that had a match in hand, this iteration (wavefront 0)
+			const u32 ng = otz_popc64 (otz_ballot (go)), np = otz_popc64 (otz_ballot (go || pend != 0));
+			OTZ_COUNT (L, J, 11, ng);
+			OTZ_COUNT (L, J, 0, np);
+		}
+		if (otz_ballot (pend != 0 || m < n_matches) == 0) {
+			break;
+		}
+		if (otz_ballot (go) == 0) { // every live lane of this wavefront waits on another wavefront
+			otz_backoff ();
+			if ((++spins & 63u) == 0) {
+				if (otz_get_status (L) != 0) {
+					break;
+				}
+				if (spins > OTZ_SPIN_LIMIT) {
+					L.dbg[0] = 3; // waited too long for source bytes
+					L.dbg[1] = otz_tid ();
+					L.dbg[2] = round_base + o;
+					L.dbg[3] = pdist | (pend << 16);
+					otz_set_status (L, OZG_ST_INTERNAL);
+					break;
+				}
+			}
+		}
+	}
+}
+
 // All OTZ_NT work-items.  Work-item 0 writes *res.
 OTZ_DEV void otz_apply_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_crc, const otz_ix_head *head, const u8 *region, ozg_result *res) {
 	const u32 tid = otz_tid ();
@@ -119,7 +348,6 @@ OTZ_DEV void otz_apply_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_cr
 			(void)otz_stage_load (L, J, byte0);
 			for (u32 i = tid; i < OTZ_RMAX / 32; i += OTZ_NT) {
 				L.fin[i] = 0;
-				L.mstart[i] = 0;
 			}
 			otz_sync ();
 			OTZ_MARK (L, J, OTZ_P_STAGE);
@@ -127,13 +355,15 @@ OTZ_DEV void otz_apply_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_cr
 			const u32 last_out = items[base + n].out;
 			const u32 produced = last_out - first.out;
 			const u32 s_bit = p0 + (a.bit - first.bit), e_bit = p0 + (z.bit - first.bit);
-			otz_place (L, tid < n, s_bit, OTZ_X_MAKE (OTZ_X_NORMAL, e_bit), opos + (a.out - first.out), opos, 0);
+			// the match list takes over the stage buffer once every lane has read its tokens
+			u16 *const list = reinterpret_cast<u16 *> (L.stage);
+			const u32 n_matches = otz_place_items (L, tid < n, s_bit, e_bit, opos + (a.out - first.out), opos, list);
 			otz_sync ();
 			OTZ_MARK (L, J, OTZ_P_EMIT);
 			if (otz_get_status (L) != 0) {
 				break;
 			}
-			otz_resolve (L, opos, produced);
+			otz_resolve_list (L, J, opos, list, n_matches);
 			otz_sync ();
 			OTZ_MARK (L, J, OTZ_P_RESOLVE);
 			if (otz_get_status (L) != 0) {

@@ -92,9 +92,16 @@ OTZ_DEV u32 otz_bfe(u32 v, u32 off, u32 width) { return __builtin_amdgcn_ubfe (v
 // low 32 bits of (hi:lo) >> (sh & 31): v_alignbit_b32
 OTZ_DEV u32 otz_alignbit(u32 hi, u32 lo, u32 sh) { return __builtin_amdgcn_alignbit (hi, lo, sh); }
 
+// low 32 bits of (hi:lo) >> (8 * (q & 3)): v_alignbyte_b32
+OTZ_DEV u32 otz_alignbyte(u32 hi, u32 lo, u32 q) { return __builtin_amdgcn_alignbyte (hi, lo, q); }
+
 // Unaligned 2/4/8-byte LDS accesses: gfx950 executes DS instructions at any byte address
-// (the compiler lowers these to single ds_read_b64 / ds_write_b32 / ... instructions), so a
-// byte-granular copy moves 8 bytes per LDS instruction instead of one.
+// (the compiler lowers these to single ds_read_b64 / ds_write_b32 / ... instructions).
+// MEASURED (tools/ubench/lds_unaligned.hip, cycles of LDS time per wave-instruction, random
+// addresses): ds_read_b64 at an arbitrary BYTE address 56 (aligned: 7.6, 4-byte aligned: 8.4);
+// ds_write_b32/_b64 at an arbitrary byte 16, ds_write_b16 5.2, ds_write_b8 3.1.  So reads on a
+// hot path fetch dword-aligned words and shift (v_alignbit / v_alignbyte); these helpers are
+// for 4-byte-aligned 8-byte reads and for stores.
 OTZ_DEV u64 otz_ld64u(const void *p) {
 	u64 v;
 	__builtin_memcpy (&v, p, 8);
@@ -111,6 +118,12 @@ OTZ_DEV void otz_st16u(void *p, u16 v) { __builtin_memcpy (p, &v, 2); }
 // Keeps the compiler from moving memory accesses across this point; emits nothing.  With
 // the in-order LDS pipeline that is all "flag, then data" needs (see otz_lds_load_inorder).
 OTZ_DEV void otz_order_loads() { asm volatile ("" ::: "memory"); }
+// Same for stores: data stores, then the flag (an LDS atomic), without waiting for the stores to
+// complete in between -- the in-order LDS queue already keeps the flag behind the data.
+OTZ_DEV void otz_order_stores() { asm volatile ("" ::: "memory"); }
+// Forces a loaded value to be materialised HERE: keeps the compiler from sinking an LDS load
+// below a branch, where it would start a second dependent round trip.
+OTZ_DEV void otz_touch64(u64 &v) { asm volatile ("" : "+v"(v)); }
 // Hides a value's origin from the optimiser: stops it from computing per-lane constants
 // once in the kernel prologue and keeping them alive (spilled) across everything else.
 OTZ_DEV u32 otz_opaque(u32 v) {

@@ -182,6 +182,8 @@ OTZ_DEV u32 otz_clz64(u64 v) { return (u32)__builtin_clzll (v); }
 OTZ_DEV u32 otz_bfe(u32 v, u32 off, u32 width) { return (v >> (off & 31u)) & ((1u << (width & 31u)) - 1u); }
 OTZ_DEV u32 otz_alignbit(u32 hi, u32 lo, u32 sh) { return (u32) ((((u64)hi << 32) | lo) >> (sh & 31u)); }
 
+OTZ_DEV u32 otz_alignbyte(u32 hi, u32 lo, u32 q) { return (u32) ((((u64)hi << 32) | lo) >> (8u * (q & 3u))); }
+
 OTZ_DEV u64 otz_ld64u(const void *p) {
 	u64 v;
 	memcpy (&v, p, 8);
@@ -196,6 +198,8 @@ OTZ_DEV void otz_st64u(void *p, u64 v) { memcpy (p, &v, 8); }
 OTZ_DEV void otz_st32u(void *p, u32 v) { memcpy (p, &v, 4); }
 OTZ_DEV void otz_st16u(void *p, u16 v) { memcpy (p, &v, 2); }
 OTZ_DEV void otz_order_loads() { __atomic_thread_fence (__ATOMIC_ACQUIRE); }
+OTZ_DEV void otz_order_stores() { __atomic_thread_fence (__ATOMIC_RELEASE); }
+OTZ_DEV void otz_touch64(u64 &v) { (void)v; }
 OTZ_DEV u32 otz_opaque(u32 v) { return v; }
 
 OTZ_DEV otz_u4 otz_ld16(const void *p) {

@@ -11,7 +11,7 @@ import torch
 import otezip_amd as oz
 from otezip_amd import corpus, _native as N
 
-NAMES = ["header", "lengths", "tables", "stage", "passA", "passB", "scan", "place", "flush", "stored", "resolve", "aux11",
+NAMES = ["res_busy#", "lengths", "tables", "stage", "passA", "passB", "scan", "place", "flush", "stored", "resolve", "res_go#",
          "rounds#", "B_iters#", "blocks#", "total"]
 
 
