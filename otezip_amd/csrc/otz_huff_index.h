@@ -34,8 +34,10 @@
 #include "otz_index.h"
 
 #define OTZ_K1_S 512u     // segment bits per lane per round
+#ifndef OTZ_K1_WARM
 #define OTZ_K1_WARM 128u  // head start of walk A (bits)
-#define OTZ_K1_SLOT 92u   // slot bytes per lane: WARM/8 before + S/8 + 12 behind; 23 dwords (odd: no bank conflicts)
+#endif
+#define OTZ_K1_SLOT (OTZ_K1_WARM / 8u + OTZ_K1_S / 8u + 12u) // slot bytes per lane: WARM/8 before + S/8 + 12 behind; 23 dwords (odd: no bank conflicts)
                           // (a walk prefetches up to three words past its slot: the next lane's, never used)
 #define OTZ_K1_NCAP (OTZ_K1_ROWS * OTZ_IX_G) // tokens a walk may take per round
 #define OTZ_K1_HDR_WORDS 264u // staged bytes for a block header: 17 + 57 + 318 x 14 bits < 1056 bytes

@@ -57,18 +57,31 @@ def test_code_object_targets_gfx950(native):
     assert "gfx950" in out
 
 
-def test_inflate_kernel_keeps_two_workgroups_per_cu(native):
-    """Occupancy is part of the design (DESIGN.md 4.1): two 512-work-item workgroups per CU
-    need <= 128 VGPRs per work-item and no scratch memory.  The build writes the compiler's
-    resource report next to the object file."""
+def _kernel_resources(name):
     rep = os.path.join(ROOT, "build", "otz_kernels.resources.txt")
     if not os.path.exists(rep):
         pytest.skip("no resource report (library was not built in this tree)")
     txt = open(rep).read()
-    m = re.search(r"Function Name: otz_inflate_kernel.*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?"
-                  r"Occupancy \[waves/SIMD\]: (\d+)", txt, flags=re.S)
-    assert m, "otz_inflate_kernel missing from the resource report"
-    vgprs, scratch, occ = map(int, m.groups())
+    m = re.search(r"Function Name: %s\b.*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?"
+                  r"Occupancy \[waves/SIMD\]: (\d+)" % name, txt, flags=re.S)
+    assert m, name + " missing from the resource report"
+    return tuple(map(int, m.groups()))
+
+
+def test_apply_kernel_keeps_two_workgroups_per_cu(native):
+    """Occupancy is part of the design (DESIGN.md 4): two 512-work-item workgroups per CU
+    need <= 128 VGPRs per work-item and no scratch memory.  The build writes the compiler's
+    resource report next to the object file."""
+    for name in ("otz_apply_kernel",):
+        vgprs, scratch, occ = _kernel_resources(name)
+        assert vgprs <= 128 and scratch == 0 and occ >= 4, (name, vgprs, scratch, occ)
+
+
+def test_index_kernel_has_no_scratch_and_four_waves_per_simd(native):
+    """One wavefront per entry, 16 of them per CU (LDS): <= 128 VGPRs.  No scratch segment:
+    spills cost the hot loops memory round trips, and on this pool a kernel with a scratch
+    segment hangs rocprofv3's --pmc passes."""
+    vgprs, scratch, occ = _kernel_resources("otz_index_kernel")
     assert vgprs <= 128 and scratch == 0 and occ >= 4, (vgprs, scratch, occ)
 
 

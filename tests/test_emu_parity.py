@@ -17,6 +17,22 @@ def _run(items):
 def test_lds_budget_allows_two_workgroups_per_cu():
     assert emu_lib().emu_lds_bytes_inflate() <= 80 * 1024
     assert emu_lib().emu_lds_bytes_copy() <= 16 * 1024
+    assert emu_lib().emu_lds_bytes_index() <= 10 * 1024  # sixteen index wavefronts per CU
+
+
+def test_workgroup_per_entry_routine_alone():
+    """The self-contained decode of otz_inflate.h (what entries take whose index overflows its arena region)."""
+    items = cases.deflate_valid(sizes=(0, 6, 1000, 20000)) + cases.deflate_tiny_f2(n=12) + cases.deflate_edge()[:30]
+    check_against_oracle(items, emu_decode(items, mode=1))
+
+
+def test_index_overflow_takes_the_fallback():
+    """No arena region at all, and regions far too small: the index kernel must say so and the
+    entries must still decode (through the overflow list)."""
+    items = cases.deflate_valid(sizes=(6, 1000, 20000))[:20] + [cases.deflate_large()[0]]
+    check_against_oracle(items, emu_decode(items, mode=2))
+    check_against_oracle(items, emu_decode(items, region_pct=12))
+    check_against_oracle(items, emu_decode(items, region_pct=20))
 
 
 def test_deflate_valid_streams():
