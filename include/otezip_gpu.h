@@ -15,6 +15,8 @@
  *   ozg_decode_batch_device   device-resident src/dst/tables, async on a stream
  *   ozg_decode_batch_device_ex  same, with a method-mix hint
  *   ozg_decode_batch_host     host buffers; stages over PCIe and waits
+ *   ozg_decode_submit / ozg_job_wait   the same, asynchronous (pinned buffers, own stream)
+ *   ozg_use_device            several GPUs from one process
  *   ozg_encode_batch_device / _host   the encode side, same conventions
  *   ozg_crc32_batch_device    otezip_crc32 (ref src/lib/crc32.inc.c:40-47) x N
  *   ozg_malloc / ozg_free / ozg_memcpy_* / ozg_stream_sync   so that host C
@@ -92,7 +94,13 @@ typedef struct ozg_limits {
 	uint64_t max_expansion_slack; /* default 1 MiB */
 } ozg_limits;
 
+/* One context per device.  ozg_init(d) prepares device d and makes it the calling thread's
+ * current one; a host that drives several GPUs of a node calls it once per device and then
+ * picks the device of the following calls with ozg_use_device(d) (per thread).  ozg_shutdown
+ * releases every context. */
 int ozg_init(int device);
+int ozg_use_device(int device);
+int ozg_current_device(void);
 void ozg_shutdown(void);
 const char *ozg_last_error(void);
 int ozg_device_count(void);
@@ -116,6 +124,19 @@ int ozg_decode_batch_device_ex(const void *d_src, uint64_t src_len, void *d_dst,
  * batch, copies dst and results back, and waits. */
 int ozg_decode_batch_host(const void *src, uint64_t src_len, void *dst, uint64_t dst_len,
 	const ozg_entry *entries, ozg_result *results, uint32_t n);
+
+/* Asynchronous form of ozg_decode_batch_host for an ingest / egress pipeline: enqueues the H2D
+ * copies, the kernels and the D2H copies on a stream of its own and returns at once.  h_src,
+ * h_dst and h_results should come from ozg_malloc_pinned (pageable memory works, but then the
+ * copies are not asynchronous); they must stay valid until the job has been waited for; the
+ * descriptor table is copied.  At most three jobs per device are in flight (OZG_E_NOMEM
+ * beyond that).  ozg_job_wait blocks until outputs and results are in host memory and
+ * releases the job; ozg_job_done polls. */
+typedef struct ozg_job ozg_job;
+int ozg_decode_submit(const void *h_src, uint64_t src_len, void *h_dst, uint64_t dst_len,
+	const ozg_entry *entries, ozg_result *h_results, uint32_t n, ozg_job **job);
+int ozg_job_done(ozg_job *job);
+int ozg_job_wait(ozg_job *job);
 
 /* ---- encode: otezip_compress_data (ref src/lib/otezip.c:788-1076) + the CRC of zip_file_add (:1124) ---- */
 

@@ -59,6 +59,11 @@ _inited = False
 _VP, _U64, _U32 = C.c_void_p, C.c_uint64, C.c_uint32
 ABI = {
     "ozg_init": (C.c_int, [C.c_int]),
+    "ozg_use_device": (C.c_int, [C.c_int]),
+    "ozg_current_device": (C.c_int, []),
+    "ozg_decode_submit": (C.c_int, [_VP, _U64, _VP, _U64, C.POINTER(OzgEntry), _VP, _U32, C.POINTER(_VP)]),
+    "ozg_job_done": (C.c_int, [_VP]),
+    "ozg_job_wait": (C.c_int, [_VP]),
     "ozg_shutdown": (None, []),
     "ozg_last_error": (C.c_char_p, []),
     "ozg_device_count": (C.c_int, []),

@@ -141,3 +141,18 @@ def build_archive(n, size, methods=(8,), workers=None, first=0):
     out += cd
     out += struct.pack("<IHHHHIIH", 0x06054B50, 0, 0, n & 0xFFFF, n & 0xFFFF, len(cd), cd_ofs, 0)
     return bytes(out), entries
+
+
+def _text_one(args):
+    return gen_text(*args)
+
+
+def text_buffers(n, size, first=0, workers=None):
+    """The n uncompressed buffers of the corpus (what build_archive compresses), for the encode side."""
+    jobs = [(first + i, size) for i in range(n)]
+    if workers is None:
+        workers = min(mp.cpu_count(), 16)
+    if workers > 1 and n >= 64:
+        with mp.get_context("fork").Pool(workers) as pool:
+            return pool.map(_text_one, jobs, chunksize=max(1, n // (workers * 8)))
+    return [_text_one(j) for j in jobs]

@@ -42,6 +42,12 @@ static_assert (sizeof (otz_ix_head) == 32 && sizeof (otz_ix_block) == 32 && size
 #define OTZ_K1_WPE 4
 #endif
 
+// the encode-side descriptor check (overflow-safe), cf. otz_entry_in_bounds
+OTZ_DEV bool otz_enc_entry_in_bounds(const ozg_enc_entry &e, u64 src_len, u64 dst_len) {
+	return e.src_off <= src_len && (u64)e.src_size <= src_len - e.src_off && (e.dst_off & 15u) == 0 && e.dst_off <= dst_len &&
+		(u64)e.dst_cap <= dst_len - e.dst_off;
+}
+
 struct otz_region {
 	u64 off;   // byte offset into the index arena
 	u32 bytes; // 0: none (descriptor out of bounds, not DEFLATE, or the arena is full)
@@ -168,7 +174,7 @@ otz_crc32_kernel(const u8 *buf, const u64 *off, const u32 *len, u32 *crc, u32 n)
 
 // DEFLATE encode / STORE of n independent buffers: one wavefront each (26 KB LDS)
 extern "C" __global__ void __launch_bounds__ (64)
-otz_encode_kernel(const u8 *src, u8 *dst, const ozg_enc_entry *entries, ozg_enc_result *results, u32 n) {
+otz_encode_kernel(const u8 *src, u8 *dst, const ozg_enc_entry *entries, ozg_enc_result *results, u32 n, u64 src_len, u64 dst_len) {
 	extern __shared__ __attribute__ ((aligned (16))) u8 otz_smem[];
 	u32 i = blockIdx.x;
 	if (i >= n) {
@@ -176,15 +182,28 @@ otz_encode_kernel(const u8 *src, u8 *dst, const ozg_enc_entry *entries, ozg_enc_
 	}
 	otz_enc_lds &L = *reinterpret_cast<otz_enc_lds *> (otz_smem);
 	ozg_enc_entry e = entries[i];
+	if (!otz_enc_entry_in_bounds (e, src_len, dst_len)) {
+		if (otz_tid () == 0) {
+			results[i].status = OZG_ST_INTERNAL;
+			results[i].comp_size = 0;
+			results[i].crc32 = 0;
+			results[i].method = e.method;
+			results[i].flags = 0;
+		}
+		return;
+	}
 	otz_encode_entry (L, src, dst, e, &results[i]);
 }
 
 // CRC-32 of every input buffer of an encode batch (ref src/lib/otezip.c:1124)
 extern "C" __global__ void __launch_bounds__ (256)
-otz_enc_crc_kernel(const u8 *src, u8 *dst, const ozg_enc_entry *entries, ozg_enc_result *results, u32 n) {
+otz_enc_crc_kernel(const u8 *src, u8 *dst, const ozg_enc_entry *entries, ozg_enc_result *results, u32 n, u64 src_len, u64 dst_len) {
 	extern __shared__ __attribute__ ((aligned (16))) u8 otz_smem[];
 	u32 i = blockIdx.x;
 	if (i >= n) {
+		return;
+	}
+	if (!otz_enc_entry_in_bounds (entries[i], src_len, dst_len)) {
 		return;
 	}
 	otz_copy_lds &L = *reinterpret_cast<otz_copy_lds *> (otz_smem);
@@ -210,25 +229,32 @@ otz_enc_crc_kernel(const u8 *src, u8 *dst, const ozg_enc_entry *entries, ozg_enc
 }
 
 // ------------------------------------------------------------------ host side
+//
+// One context per HIP device (staging buffers, the index arena, the slots of the asynchronous
+// staged batches): nothing here is process-global but the table of contexts, so a host can
+// drive several GPUs of a node from one process -- ozg_init(d) once per device, ozg_use_device(d)
+// to pick the one the following calls use (per thread).  Every entry point selects its device
+// first: hipSetDevice is per host thread.
 
 namespace {
 
-std::mutex g_mu;
-std::mutex g_ws_mu;
+constexpr int MAX_DEV = 16;
+constexpr int N_SLOTS = 3; // asynchronous staged batches in flight per device
+
+std::mutex g_mu; // contexts, their buffers and slots
 u32 g_chunks = 1; // chunks of a large DEFLATE batch on two internal streams (OTEZIP_GPU_CHUNKS): measured slower than one launch pair (4.1 -> 4.4 ms at 4), kept for experiments
-bool g_ready = false;
-int g_device = -1;
 ozg_limits g_limits = { 1000ull, 1024ull * 1024ull };
 u64 *g_prof = nullptr; // diagnostics: per-entry phase cycle counters (ozg_debug_set_profile_buffer)
 thread_local char g_err[256] = "";
+thread_local int g_cur = -1; // this thread's device (ozg_init / ozg_use_device)
+int g_default = -1;          // the device of the first successful ozg_init: what a thread starts with
 
 struct staging {
 	void *d_src = nullptr, *d_dst = nullptr, *d_ent = nullptr, *d_res = nullptr;
 	size_t src_cap = 0, dst_cap = 0, ent_cap = 0, res_cap = 0;
-} g_stage;
+};
 
-// Index arena of the DEFLATE path.  One per library (device); batches on different streams
-// are ordered through `done`.
+// Index arena of the DEFLATE path; batches on different streams are ordered through `done`.
 struct workspace {
 	u8 *arena = nullptr;
 	size_t arena_cap = 0;
@@ -239,11 +265,31 @@ struct workspace {
 	u32 *ovf = nullptr; // overflow list: count, then entry numbers
 	hipEvent_t done = nullptr;
 	bool busy = false;
-	// a large batch is cut into chunks that alternate between two internal streams, so that the
-	// index kernel of one chunk runs beside the apply kernel of another
 	hipStream_t aux[2] = { nullptr, nullptr };
 	hipEvent_t fork = nullptr, join[2] = { nullptr, nullptr };
-} g_ws;
+};
+
+} // namespace
+
+// an asynchronous staged batch: H2D, kernels, D2H on a stream of its own
+struct ozg_job {
+	int dev = -1;
+	bool busy = false;
+	hipStream_t stream = nullptr;
+	hipEvent_t done = nullptr;
+	staging st;
+	void *h_ent = nullptr; // pinned copy of the descriptor table
+	size_t h_ent_cap = 0;
+};
+
+namespace {
+
+struct dev_ctx {
+	bool ready = false;
+	staging stage; // synchronous host entry points
+	workspace ws;
+	ozg_job slots[N_SLOTS];
+} g_dev[MAX_DEV];
 
 int fail_hip(const char *what, hipError_t e) {
 	snprintf (g_err, sizeof (g_err), "%s: %s", what, hipGetErrorString (e));
@@ -258,11 +304,16 @@ int fail_hip(const char *what, hipError_t e) {
 		} \
 	} while (0)
 
-int need_ready() {
-	if (!g_ready) {
+// the calling thread's context; selects its device
+int need_ctx(dev_ctx **out) {
+	int d = g_cur >= 0 ? g_cur : g_default;
+	if (d < 0 || !g_dev[d].ready) {
 		snprintf (g_err, sizeof (g_err), "ozg_init() has not succeeded: no HIP device, and this library has no CPU path");
 		return OZG_E_NODEVICE;
 	}
+	OZG_HIP (hipSetDevice (d));
+	g_cur = d;
+	*out = &g_dev[d];
 	return OZG_OK;
 }
 
@@ -278,6 +329,170 @@ int grow(void **p, size_t *cap, size_t want) {
 	size_t sz = want < 4096 ? 4096 : want;
 	OZG_HIP (hipMalloc (p, sz));
 	*cap = sz;
+	return OZG_OK;
+}
+
+void staging_free(staging &s) {
+	(void)hipFree (s.d_src);
+	(void)hipFree (s.d_dst);
+	(void)hipFree (s.d_ent);
+	(void)hipFree (s.d_res);
+	s = staging ();
+}
+
+int staging_reserve(staging &s, size_t src, size_t dst, size_t ent, size_t res) {
+	int rc;
+	if ((rc = grow (&s.d_src, &s.src_cap, src)) != OZG_OK || (rc = grow (&s.d_dst, &s.dst_cap, dst)) != OZG_OK ||
+		(rc = grow (&s.d_ent, &s.ent_cap, ent)) != OZG_OK || (rc = grow (&s.d_res, &s.res_cap, res)) != OZG_OK) {
+		return rc;
+	}
+	return OZG_OK;
+}
+
+// Room for the index of a batch: every entry asks for otz_ix_region_bytes(); their sum is
+// bounded by the buffer sizes (dst regions do not overlap).  Entries that find the arena
+// full are decoded by the self-contained kernel instead.
+int ws_reserve(workspace &ws, uint64_t src_len, uint64_t dst_len, uint32_t n) {
+	const size_t per_entry = 4096u + OTZ_K1_TEMP_BYTES + 256u;
+	size_t want = (size_t)dst_len + (size_t) (src_len >> 1) + (size_t)n * per_entry;
+	if (want > ((size_t)8 << 30)) {
+		want = (size_t)8 << 30; // beyond that, the overflow path takes what does not fit
+	}
+	if (!ws.done) {
+		OZG_HIP (hipEventCreateWithFlags (&ws.done, hipEventDisableTiming));
+	}
+	if (!ws.cursor) {
+		OZG_HIP (hipMalloc ((void **)&ws.cursor, 256));
+	}
+	if (!ws.fork) {
+		OZG_HIP (hipEventCreateWithFlags (&ws.fork, hipEventDisableTiming));
+		for (int k = 0; k < 2; k++) {
+			OZG_HIP (hipStreamCreateWithFlags (&ws.aux[k], hipStreamNonBlocking));
+			OZG_HIP (hipEventCreateWithFlags (&ws.join[k], hipEventDisableTiming));
+		}
+	}
+	if (want > ws.arena_cap || n > ws.n_cap) {
+		OZG_HIP (hipDeviceSynchronize ()); // earlier batches may still read what is about to be freed
+		ws.busy = false;
+	}
+	if (want > ws.arena_cap) {
+		if (ws.arena) {
+			(void)hipFree (ws.arena);
+			ws.arena = nullptr;
+			ws.arena_cap = 0;
+		}
+		want += want >> 2; // (some head room: the next, slightly larger batch should not reallocate)
+		OZG_HIP (hipMalloc ((void **)&ws.arena, want));
+		ws.arena_cap = want;
+	}
+	if (n > ws.n_cap) {
+		(void)hipFree (ws.regions);
+		(void)hipFree (ws.heads);
+		(void)hipFree (ws.ovf);
+		ws.regions = nullptr;
+		ws.heads = nullptr;
+		ws.ovf = nullptr;
+		ws.n_cap = 0;
+		const size_t cap = n < 1024u ? 1024u : n + (n >> 2);
+		OZG_HIP (hipMalloc ((void **)&ws.regions, cap * sizeof (otz_region)));
+		OZG_HIP (hipMalloc ((void **)&ws.heads, cap * sizeof (otz_ix_head)));
+		OZG_HIP (hipMalloc ((void **)&ws.ovf, (cap + 1u) * sizeof (u32)));
+		ws.n_cap = cap;
+	}
+	return OZG_OK;
+}
+
+void ws_free(workspace &ws) {
+	(void)hipFree (ws.arena);
+	(void)hipFree (ws.regions);
+	(void)hipFree (ws.heads);
+	(void)hipFree (ws.cursor);
+	(void)hipFree (ws.ovf);
+	if (ws.done) {
+		(void)hipEventDestroy (ws.done);
+	}
+	if (ws.fork) {
+		(void)hipEventDestroy (ws.fork);
+		for (int k = 0; k < 2; k++) {
+			(void)hipStreamDestroy (ws.aux[k]);
+			(void)hipEventDestroy (ws.join[k]);
+		}
+	}
+	ws = workspace ();
+}
+
+// the launches of one decode batch on stream s (device pointers); the caller holds g_mu
+int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, uint64_t dst_len, const ozg_entry *d_entries,
+	ozg_result *d_results, uint32_t n, hipStream_t s, uint32_t batch_flags) {
+	int rc;
+	if (!(batch_flags & OZG_BATCH_NO_DEFLATE)) {
+		workspace &ws = C.ws;
+		if ((rc = ws_reserve (ws, src_len, dst_len, n)) != OZG_OK) {
+			return rc;
+		}
+		if (ws.busy) {
+			OZG_HIP (hipStreamWaitEvent (s, ws.done, 0)); // the arena is shared between streams
+		}
+		OZG_HIP (hipMemsetAsync (ws.cursor, 0, 8, s));
+		OZG_HIP (hipMemsetAsync (ws.ovf, 0, 4, s));
+		hipLaunchKernelGGL (otz_plan_kernel, dim3 ((n + 255u) / 256u), dim3 (256), 0, s, d_entries, n, (u64)src_len, (u64)dst_len,
+			(u64)ws.arena_cap, ws.cursor, ws.regions, ws.heads);
+		OZG_HIP (hipGetLastError ());
+		const u32 n_chunks = n >= 4096u ? g_chunks : 1u;
+		if (n_chunks <= 1u) {
+			hipLaunchKernelGGL (otz_index_kernel, dim3 (n), dim3 (64), sizeof (otz_k1_lds), s, (const u8 *)d_src, (u8 *)d_dst, d_entries, 0u, n,
+				(u64)src_len, (u64)dst_len, g_limits, ws.arena, ws.regions, ws.heads, ws.ovf, g_prof);
+			OZG_HIP (hipGetLastError ());
+			hipLaunchKernelGGL (otz_apply_kernel, dim3 (n), dim3 (OTZ_NT), sizeof (otz_inflate_lds), s, (const u8 *)d_src, (u8 *)d_dst,
+				d_entries, d_results, 0u, n, (u64)src_len, (u64)dst_len, g_limits, (const u8 *)ws.arena, ws.regions, ws.heads, g_prof);
+			OZG_HIP (hipGetLastError ());
+		} else {
+			OZG_HIP (hipEventRecord (ws.fork, s));
+			for (int k = 0; k < 2; k++) {
+				OZG_HIP (hipStreamWaitEvent (ws.aux[k], ws.fork, 0));
+			}
+			for (u32 c = 0; c < n_chunks; c++) {
+				const u32 e0 = (u32) ((u64)n * c / n_chunks), e1 = (u32) ((u64)n * (c + 1u) / n_chunks);
+				hipStream_t cs = ws.aux[c & 1u];
+				hipLaunchKernelGGL (otz_index_kernel, dim3 (e1 - e0), dim3 (64), sizeof (otz_k1_lds), cs, (const u8 *)d_src, (u8 *)d_dst, d_entries, e0, n,
+					(u64)src_len, (u64)dst_len, g_limits, ws.arena, ws.regions, ws.heads, ws.ovf, g_prof);
+				OZG_HIP (hipGetLastError ());
+				hipLaunchKernelGGL (otz_apply_kernel, dim3 (e1 - e0), dim3 (OTZ_NT), sizeof (otz_inflate_lds), cs, (const u8 *)d_src, (u8 *)d_dst,
+					d_entries, d_results, e0, n, (u64)src_len, (u64)dst_len, g_limits, (const u8 *)ws.arena, ws.regions, ws.heads, g_prof);
+				OZG_HIP (hipGetLastError ());
+			}
+			for (int k = 0; k < 2; k++) {
+				OZG_HIP (hipEventRecord (ws.join[k], ws.aux[k]));
+				OZG_HIP (hipStreamWaitEvent (s, ws.join[k], 0));
+			}
+		}
+		hipLaunchKernelGGL (otz_inflate_kernel, dim3 (n < 256u ? n : 256u), dim3 (OTZ_NT), sizeof (otz_inflate_lds), s, (const u8 *)d_src,
+			(u8 *)d_dst, d_entries, d_results, g_limits, (const u32 *)ws.ovf);
+		OZG_HIP (hipGetLastError ());
+		OZG_HIP (hipEventRecord (ws.done, s));
+		ws.busy = true;
+	}
+	if (!(batch_flags & OZG_BATCH_ONLY_DEFLATE)) {
+		hipLaunchKernelGGL (otz_copy_kernel, dim3 (n), dim3 (256), sizeof (otz_copy_lds), s, (const u8 *)d_src,
+			(u8 *)d_dst, d_entries, d_results, n, (u64)src_len, (u64)dst_len, g_limits);
+		OZG_HIP (hipGetLastError ());
+	}
+	return OZG_OK;
+}
+
+// host-side view of a descriptor table: bounds, and which launches it needs
+int check_entries(const ozg_entry *entries, uint32_t n, uint64_t src_len, uint64_t dst_len, uint32_t *flags) {
+	uint32_t f = OZG_BATCH_NO_DEFLATE | OZG_BATCH_ONLY_DEFLATE;
+	for (uint32_t i = 0; i < n; i++) {
+		const ozg_entry &e = entries[i];
+		if (e.src_off > src_len || e.comp_size > src_len - e.src_off || (e.dst_off & 15u) || e.dst_off > dst_len ||
+			e.uncomp_size > dst_len - e.dst_off) {
+			snprintf (g_err, sizeof (g_err), "entry %u: offsets outside the buffers or dst_off not a multiple of 16", i);
+			return OZG_E_ARG;
+		}
+		f &= e.method == OZG_METHOD_DEFLATE ? ~OZG_BATCH_NO_DEFLATE : ~OZG_BATCH_ONLY_DEFLATE;
+	}
+	*flags = f;
 	return OZG_OK;
 }
 
@@ -304,81 +519,84 @@ int ozg_init(int device) {
 			e == hipSuccess ? "device count 0" : hipGetErrorString (e));
 		return OZG_E_NODEVICE;
 	}
-	if (device < 0 || device >= n) {
-		snprintf (g_err, sizeof (g_err), "device %d out of range (0..%d)", device, n - 1);
+	if (device < 0 || device >= n || device >= MAX_DEV) {
+		snprintf (g_err, sizeof (g_err), "device %d out of range (0..%d)", device, (n < MAX_DEV ? n : MAX_DEV) - 1);
 		return OZG_E_ARG;
 	}
 	OZG_HIP (hipSetDevice (device));
-	OZG_HIP (hipFuncSetAttribute ((const void *)otz_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-		(int)sizeof (otz_inflate_lds)));
-	OZG_HIP (hipFuncSetAttribute ((const void *)otz_inflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-		(int)sizeof (otz_inflate_lds)));
-	OZG_HIP (hipFuncSetAttribute ((const void *)otz_index_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-		(int)sizeof (otz_k1_lds)));
-	OZG_HIP (hipFuncSetAttribute ((const void *)otz_copy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-		(int)sizeof (otz_copy_lds)));
-	OZG_HIP (hipFuncSetAttribute ((const void *)otz_crc32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-		(int)sizeof (otz_copy_lds)));
-	OZG_HIP (hipFuncSetAttribute ((const void *)otz_enc_crc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-		(int)sizeof (otz_copy_lds)));
-	OZG_HIP (hipFuncSetAttribute ((const void *)otz_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-		(int)sizeof (otz_enc_lds)));
+	if (!g_dev[device].ready) {
+		// (function attributes are per device)
+		OZG_HIP (hipFuncSetAttribute ((const void *)otz_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+			(int)sizeof (otz_inflate_lds)));
+		OZG_HIP (hipFuncSetAttribute ((const void *)otz_inflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+			(int)sizeof (otz_inflate_lds)));
+		OZG_HIP (hipFuncSetAttribute ((const void *)otz_index_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+			(int)sizeof (otz_k1_lds)));
+		OZG_HIP (hipFuncSetAttribute ((const void *)otz_copy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+			(int)sizeof (otz_copy_lds)));
+		OZG_HIP (hipFuncSetAttribute ((const void *)otz_crc32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+			(int)sizeof (otz_copy_lds)));
+		OZG_HIP (hipFuncSetAttribute ((const void *)otz_enc_crc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+			(int)sizeof (otz_copy_lds)));
+		OZG_HIP (hipFuncSetAttribute ((const void *)otz_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+			(int)sizeof (otz_enc_lds)));
+		g_dev[device].ready = true;
+	}
 	if (const char *c = getenv ("OTEZIP_GPU_CHUNKS")) {
 		const int v = atoi (c);
 		g_chunks = v < 1 ? 1u : v > 64 ? 64u : (u32)v;
 	}
-	g_device = device;
-	g_ready = true;
+	g_cur = device;
+	if (g_default < 0) {
+		g_default = device;
+	}
 	g_err[0] = 0;
 	return OZG_OK;
 }
 
+int ozg_use_device(int device) {
+	if (device < 0 || device >= MAX_DEV || !g_dev[device].ready) {
+		snprintf (g_err, sizeof (g_err), "device %d has not been initialised with ozg_init()", device);
+		return OZG_E_ARG;
+	}
+	OZG_HIP (hipSetDevice (device));
+	g_cur = device;
+	return OZG_OK;
+}
+
+int ozg_current_device(void) { return g_cur >= 0 ? g_cur : g_default; }
+
 void ozg_shutdown(void) {
 	std::lock_guard<std::mutex> lk (g_mu);
-	if (!g_ready) {
-		return;
-	}
-	(void)hipDeviceSynchronize ();
-	if (g_stage.d_src) {
-		(void)hipFree (g_stage.d_src);
-	}
-	if (g_stage.d_dst) {
-		(void)hipFree (g_stage.d_dst);
-	}
-	if (g_stage.d_ent) {
-		(void)hipFree (g_stage.d_ent);
-	}
-	if (g_stage.d_res) {
-		(void)hipFree (g_stage.d_res);
-	}
-	g_stage = staging ();
-	if (g_ws.arena) {
-		(void)hipFree (g_ws.arena);
-	}
-	if (g_ws.regions) {
-		(void)hipFree (g_ws.regions);
-	}
-	if (g_ws.heads) {
-		(void)hipFree (g_ws.heads);
-	}
-	if (g_ws.cursor) {
-		(void)hipFree (g_ws.cursor);
-	}
-	if (g_ws.ovf) {
-		(void)hipFree (g_ws.ovf);
-	}
-	if (g_ws.done) {
-		(void)hipEventDestroy (g_ws.done);
-	}
-	if (g_ws.fork) {
-		(void)hipEventDestroy (g_ws.fork);
-		for (int k = 0; k < 2; k++) {
-			(void)hipStreamDestroy (g_ws.aux[k]);
-			(void)hipEventDestroy (g_ws.join[k]);
+	for (int d = 0; d < MAX_DEV; d++) {
+		dev_ctx &C = g_dev[d];
+		if (!C.ready) {
+			continue;
 		}
+		if (hipSetDevice (d) != hipSuccess) {
+			continue;
+		}
+		(void)hipDeviceSynchronize ();
+		staging_free (C.stage);
+		ws_free (C.ws);
+		for (int k = 0; k < N_SLOTS; k++) {
+			ozg_job &j = C.slots[k];
+			staging_free (j.st);
+			if (j.h_ent) {
+				(void)hipHostFree (j.h_ent);
+			}
+			if (j.stream) {
+				(void)hipStreamDestroy (j.stream);
+			}
+			if (j.done) {
+				(void)hipEventDestroy (j.done);
+			}
+			j = ozg_job ();
+		}
+		C.ready = false;
 	}
-	g_ws = workspace ();
-	g_ready = false;
+	g_default = -1;
+	g_cur = -1;
 }
 
 void ozg_set_limits(const ozg_limits *lim) {
@@ -387,67 +605,10 @@ void ozg_set_limits(const ozg_limits *lim) {
 	}
 }
 
-// Room for the index of a batch: every entry asks for otz_ix_region_bytes(); their sum is
-// bounded by the buffer sizes (dst regions do not overlap).  Entries that find the arena
-// full are decoded by the apply kernel's self-contained routine instead.
-static int ws_reserve(uint64_t src_len, uint64_t dst_len, uint32_t n) {
-	const size_t per_entry = 4096u + OTZ_K1_TEMP_BYTES + 256u;
-	size_t want = (size_t)dst_len + (size_t) (src_len >> 1) + (size_t)n * per_entry;
-	if (want > ((size_t)8 << 30)) {
-		want = (size_t)8 << 30; // beyond that, the overflow path takes what does not fit
-	}
-	if (!g_ws.done) {
-		OZG_HIP (hipEventCreateWithFlags (&g_ws.done, hipEventDisableTiming));
-	}
-	if (!g_ws.cursor) {
-		OZG_HIP (hipMalloc ((void **)&g_ws.cursor, 256));
-	}
-	if (!g_ws.fork) {
-		OZG_HIP (hipEventCreateWithFlags (&g_ws.fork, hipEventDisableTiming));
-		for (int k = 0; k < 2; k++) {
-			OZG_HIP (hipStreamCreateWithFlags (&g_ws.aux[k], hipStreamNonBlocking));
-			OZG_HIP (hipEventCreateWithFlags (&g_ws.join[k], hipEventDisableTiming));
-		}
-	}
-	if (want > g_ws.arena_cap || n > g_ws.n_cap) {
-		OZG_HIP (hipDeviceSynchronize ()); // earlier batches may still read what is about to be freed
-		g_ws.busy = false;
-	}
-	if (want > g_ws.arena_cap) {
-		if (g_ws.arena) {
-			(void)hipFree (g_ws.arena);
-			g_ws.arena = nullptr;
-			g_ws.arena_cap = 0;
-		}
-		OZG_HIP (hipMalloc ((void **)&g_ws.arena, want));
-		g_ws.arena_cap = want;
-	}
-	if (n > g_ws.n_cap) {
-		if (g_ws.regions) {
-			(void)hipFree (g_ws.regions);
-			g_ws.regions = nullptr;
-		}
-		if (g_ws.heads) {
-			(void)hipFree (g_ws.heads);
-			g_ws.heads = nullptr;
-		}
-		if (g_ws.ovf) {
-			(void)hipFree (g_ws.ovf);
-			g_ws.ovf = nullptr;
-		}
-		g_ws.n_cap = 0;
-		const size_t cap = n < 1024u ? 1024u : n;
-		OZG_HIP (hipMalloc ((void **)&g_ws.regions, cap * sizeof (otz_region)));
-		OZG_HIP (hipMalloc ((void **)&g_ws.heads, cap * sizeof (otz_ix_head)));
-		OZG_HIP (hipMalloc ((void **)&g_ws.ovf, (cap + 1u) * sizeof (u32)));
-		g_ws.n_cap = cap;
-	}
-	return OZG_OK;
-}
-
 int ozg_decode_batch_device_ex(const void *d_src, uint64_t src_len, void *d_dst, uint64_t dst_len,
 	const ozg_entry *d_entries, ozg_result *d_results, uint32_t n, void *stream, uint32_t batch_flags) {
-	int rc = need_ready ();
+	dev_ctx *C;
+	int rc = need_ctx (&C);
 	if (rc != OZG_OK) {
 		return rc;
 	}
@@ -462,60 +623,8 @@ int ozg_decode_batch_device_ex(const void *d_src, uint64_t src_len, void *d_dst,
 		snprintf (g_err, sizeof (g_err), "d_dst must be 16-byte aligned");
 		return OZG_E_ARG;
 	}
-	hipStream_t s = (hipStream_t)stream;
-	if (!(batch_flags & OZG_BATCH_NO_DEFLATE)) {
-		std::lock_guard<std::mutex> lk (g_ws_mu);
-		if ((rc = ws_reserve (src_len, dst_len, n)) != OZG_OK) {
-			return rc;
-		}
-		if (g_ws.busy) {
-			OZG_HIP (hipStreamWaitEvent (s, g_ws.done, 0)); // the arena is shared between streams
-		}
-		OZG_HIP (hipMemsetAsync (g_ws.cursor, 0, 8, s));
-		OZG_HIP (hipMemsetAsync (g_ws.ovf, 0, 4, s));
-		hipLaunchKernelGGL (otz_plan_kernel, dim3 ((n + 255u) / 256u), dim3 (256), 0, s, d_entries, n, (u64)src_len, (u64)dst_len,
-			(u64)g_ws.arena_cap, g_ws.cursor, g_ws.regions, g_ws.heads);
-		OZG_HIP (hipGetLastError ());
-		const u32 n_chunks = n >= 4096u ? g_chunks : 1u;
-		if (n_chunks <= 1u) {
-			hipLaunchKernelGGL (otz_index_kernel, dim3 (n), dim3 (64), sizeof (otz_k1_lds), s, (const u8 *)d_src, (u8 *)d_dst, d_entries, 0u, n,
-				(u64)src_len, (u64)dst_len, g_limits, g_ws.arena, g_ws.regions, g_ws.heads, g_ws.ovf, g_prof);
-			OZG_HIP (hipGetLastError ());
-			hipLaunchKernelGGL (otz_apply_kernel, dim3 (n), dim3 (OTZ_NT), sizeof (otz_inflate_lds), s, (const u8 *)d_src, (u8 *)d_dst,
-				d_entries, d_results, 0u, n, (u64)src_len, (u64)dst_len, g_limits, (const u8 *)g_ws.arena, g_ws.regions, g_ws.heads, g_prof);
-			OZG_HIP (hipGetLastError ());
-		} else {
-			OZG_HIP (hipEventRecord (g_ws.fork, s));
-			for (int k = 0; k < 2; k++) {
-				OZG_HIP (hipStreamWaitEvent (g_ws.aux[k], g_ws.fork, 0));
-			}
-			for (u32 c = 0; c < n_chunks; c++) {
-				const u32 e0 = (u32) ((u64)n * c / n_chunks), e1 = (u32) ((u64)n * (c + 1u) / n_chunks);
-				hipStream_t cs = g_ws.aux[c & 1u];
-				hipLaunchKernelGGL (otz_index_kernel, dim3 (e1 - e0), dim3 (64), sizeof (otz_k1_lds), cs, (const u8 *)d_src, (u8 *)d_dst, d_entries, e0, n,
-					(u64)src_len, (u64)dst_len, g_limits, g_ws.arena, g_ws.regions, g_ws.heads, g_ws.ovf, g_prof);
-				OZG_HIP (hipGetLastError ());
-				hipLaunchKernelGGL (otz_apply_kernel, dim3 (e1 - e0), dim3 (OTZ_NT), sizeof (otz_inflate_lds), cs, (const u8 *)d_src, (u8 *)d_dst,
-					d_entries, d_results, e0, n, (u64)src_len, (u64)dst_len, g_limits, (const u8 *)g_ws.arena, g_ws.regions, g_ws.heads, g_prof);
-				OZG_HIP (hipGetLastError ());
-			}
-			for (int k = 0; k < 2; k++) {
-				OZG_HIP (hipEventRecord (g_ws.join[k], g_ws.aux[k]));
-				OZG_HIP (hipStreamWaitEvent (s, g_ws.join[k], 0));
-			}
-		}
-		hipLaunchKernelGGL (otz_inflate_kernel, dim3 (n < 256u ? n : 256u), dim3 (OTZ_NT), sizeof (otz_inflate_lds), s, (const u8 *)d_src,
-			(u8 *)d_dst, d_entries, d_results, g_limits, (const u32 *)g_ws.ovf);
-		OZG_HIP (hipGetLastError ());
-		OZG_HIP (hipEventRecord (g_ws.done, s));
-		g_ws.busy = true;
-	}
-	if (!(batch_flags & OZG_BATCH_ONLY_DEFLATE)) {
-		hipLaunchKernelGGL (otz_copy_kernel, dim3 (n), dim3 (256), sizeof (otz_copy_lds), s, (const u8 *)d_src,
-			(u8 *)d_dst, d_entries, d_results, n, (u64)src_len, (u64)dst_len, g_limits);
-		OZG_HIP (hipGetLastError ());
-	}
-	return OZG_OK;
+	std::lock_guard<std::mutex> lk (g_mu);
+	return launch_decode (*C, d_src, src_len, d_dst, dst_len, d_entries, d_results, n, (hipStream_t)stream, batch_flags);
 }
 
 int ozg_decode_batch_device(const void *d_src, uint64_t src_len, void *d_dst, uint64_t dst_len,
@@ -525,7 +634,8 @@ int ozg_decode_batch_device(const void *d_src, uint64_t src_len, void *d_dst, ui
 
 int ozg_decode_batch_host(const void *src, uint64_t src_len, void *dst, uint64_t dst_len,
 	const ozg_entry *entries, ozg_result *results, uint32_t n) {
-	int rc = need_ready ();
+	dev_ctx *C;
+	int rc = need_ctx (&C);
 	if (rc != OZG_OK) {
 		return rc;
 	}
@@ -536,38 +646,116 @@ int ozg_decode_batch_host(const void *src, uint64_t src_len, void *dst, uint64_t
 		snprintf (g_err, sizeof (g_err), "null pointer");
 		return OZG_E_ARG;
 	}
-	uint32_t flags = OZG_BATCH_NO_DEFLATE | OZG_BATCH_ONLY_DEFLATE;
-	for (uint32_t i = 0; i < n; i++) {
-		const ozg_entry &e = entries[i];
-		if (e.src_off + e.comp_size > src_len || (e.dst_off & 15u) || e.dst_off + e.uncomp_size > dst_len) {
-			snprintf (g_err, sizeof (g_err), "entry %u: offsets outside the buffers or dst_off not a multiple of 16", i);
-			return OZG_E_ARG;
-		}
-		flags &= e.method == OZG_METHOD_DEFLATE ? ~OZG_BATCH_NO_DEFLATE : ~OZG_BATCH_ONLY_DEFLATE;
+	uint32_t flags;
+	if ((rc = check_entries (entries, n, src_len, dst_len, &flags)) != OZG_OK) {
+		return rc;
 	}
 	std::lock_guard<std::mutex> lk (g_mu);
-	if ((rc = grow (&g_stage.d_src, &g_stage.src_cap, src_len + 64)) != OZG_OK) {
+	staging &S = C->stage;
+	if ((rc = staging_reserve (S, src_len + 64, dst_len + 64, (size_t)n * sizeof (ozg_entry), (size_t)n * sizeof (ozg_result))) != OZG_OK) {
 		return rc;
 	}
-	if ((rc = grow (&g_stage.d_dst, &g_stage.dst_cap, dst_len + 64)) != OZG_OK) {
-		return rc;
-	}
-	if ((rc = grow (&g_stage.d_ent, &g_stage.ent_cap, (size_t)n * sizeof (ozg_entry))) != OZG_OK) {
-		return rc;
-	}
-	if ((rc = grow (&g_stage.d_res, &g_stage.res_cap, (size_t)n * sizeof (ozg_result))) != OZG_OK) {
-		return rc;
-	}
-	OZG_HIP (hipMemcpyAsync (g_stage.d_src, src, src_len, hipMemcpyHostToDevice, nullptr));
-	OZG_HIP (hipMemcpyAsync (g_stage.d_ent, entries, (size_t)n * sizeof (ozg_entry), hipMemcpyHostToDevice, nullptr));
-	rc = ozg_decode_batch_device_ex (g_stage.d_src, src_len, g_stage.d_dst, dst_len, (const ozg_entry *)g_stage.d_ent,
-		(ozg_result *)g_stage.d_res, n, nullptr, flags);
+	OZG_HIP (hipMemcpyAsync (S.d_src, src, src_len, hipMemcpyHostToDevice, nullptr));
+	OZG_HIP (hipMemcpyAsync (S.d_ent, entries, (size_t)n * sizeof (ozg_entry), hipMemcpyHostToDevice, nullptr));
+	rc = launch_decode (*C, S.d_src, src_len, S.d_dst, dst_len, (const ozg_entry *)S.d_ent, (ozg_result *)S.d_res, n, nullptr, flags);
 	if (rc != OZG_OK) {
 		return rc;
 	}
-	OZG_HIP (hipMemcpyAsync (dst, g_stage.d_dst, dst_len, hipMemcpyDeviceToHost, nullptr));
-	OZG_HIP (hipMemcpyAsync (results, g_stage.d_res, (size_t)n * sizeof (ozg_result), hipMemcpyDeviceToHost, nullptr));
+	OZG_HIP (hipMemcpyAsync (dst, S.d_dst, dst_len, hipMemcpyDeviceToHost, nullptr));
+	OZG_HIP (hipMemcpyAsync (results, S.d_res, (size_t)n * sizeof (ozg_result), hipMemcpyDeviceToHost, nullptr));
 	OZG_HIP (hipStreamSynchronize (nullptr));
+	return OZG_OK;
+}
+
+// ---- asynchronous staged batches: the ingest / egress pipeline of the zip layer
+
+int ozg_decode_submit(const void *h_src, uint64_t src_len, void *h_dst, uint64_t dst_len, const ozg_entry *entries,
+	ozg_result *h_results, uint32_t n, ozg_job **job) {
+	dev_ctx *C;
+	int rc = need_ctx (&C);
+	if (rc != OZG_OK) {
+		return rc;
+	}
+	if (!job || !h_src || !h_dst || !entries || !h_results || n == 0) {
+		snprintf (g_err, sizeof (g_err), "null pointer or empty batch");
+		return OZG_E_ARG;
+	}
+	uint32_t flags;
+	if ((rc = check_entries (entries, n, src_len, dst_len, &flags)) != OZG_OK) {
+		return rc;
+	}
+	std::lock_guard<std::mutex> lk (g_mu);
+	ozg_job *J = nullptr;
+	for (int k = 0; k < N_SLOTS; k++) {
+		if (!C->slots[k].busy) {
+			J = &C->slots[k];
+			break;
+		}
+	}
+	if (!J) {
+		snprintf (g_err, sizeof (g_err), "all %d staged-batch slots of the device are in flight", N_SLOTS);
+		return OZG_E_NOMEM;
+	}
+	if (!J->stream) {
+		OZG_HIP (hipStreamCreateWithFlags (&J->stream, hipStreamNonBlocking));
+		OZG_HIP (hipEventCreateWithFlags (&J->done, hipEventDisableTiming));
+	}
+	J->dev = g_cur;
+	const size_t ent_bytes = (size_t)n * sizeof (ozg_entry);
+	if ((rc = staging_reserve (J->st, src_len + 64, dst_len + 64, ent_bytes, (size_t)n * sizeof (ozg_result))) != OZG_OK) {
+		return rc;
+	}
+	if (ent_bytes > J->h_ent_cap) {
+		if (J->h_ent) {
+			(void)hipHostFree (J->h_ent);
+			J->h_ent = nullptr;
+			J->h_ent_cap = 0;
+		}
+		OZG_HIP (hipHostMalloc (&J->h_ent, ent_bytes + (ent_bytes >> 1), hipHostMallocDefault));
+		J->h_ent_cap = ent_bytes + (ent_bytes >> 1);
+	}
+	memcpy (J->h_ent, entries, ent_bytes); // (the caller's table may be gone before the copy runs)
+	hipStream_t s = J->stream;
+	OZG_HIP (hipMemcpyAsync (J->st.d_src, h_src, src_len, hipMemcpyHostToDevice, s));
+	OZG_HIP (hipMemcpyAsync (J->st.d_ent, J->h_ent, ent_bytes, hipMemcpyHostToDevice, s));
+	rc = launch_decode (*C, J->st.d_src, src_len, J->st.d_dst, dst_len, (const ozg_entry *)J->st.d_ent, (ozg_result *)J->st.d_res, n, s, flags);
+	if (rc != OZG_OK) {
+		return rc;
+	}
+	OZG_HIP (hipMemcpyAsync (h_dst, J->st.d_dst, dst_len, hipMemcpyDeviceToHost, s));
+	OZG_HIP (hipMemcpyAsync (h_results, J->st.d_res, (size_t)n * sizeof (ozg_result), hipMemcpyDeviceToHost, s));
+	OZG_HIP (hipEventRecord (J->done, s));
+	J->busy = true;
+	*job = J;
+	return OZG_OK;
+}
+
+int ozg_job_done(ozg_job *job) {
+	if (!job || !job->busy) {
+		return 1;
+	}
+	return hipEventQuery (job->done) == hipSuccess ? 1 : 0;
+}
+
+int ozg_job_wait(ozg_job *job) {
+	if (!job || !job->busy) {
+		return OZG_OK;
+	}
+	const int keep = g_cur;
+	if (hipSetDevice (job->dev) != hipSuccess) {
+		return OZG_E_HIP;
+	}
+	hipError_t e = hipEventSynchronize (job->done);
+	{
+		std::lock_guard<std::mutex> lk (g_mu);
+		job->busy = false;
+	}
+	if (keep >= 0 && keep != job->dev) {
+		(void)hipSetDevice (keep);
+	}
+	if (e != hipSuccess) {
+		return fail_hip ("hipEventSynchronize", e);
+	}
 	return OZG_OK;
 }
 
@@ -586,12 +774,11 @@ uint64_t ozg_compress_bound(uint16_t method, uint64_t n) {
 
 int ozg_encode_batch_device(const void *d_src, uint64_t src_len, void *d_dst, uint64_t dst_len,
 	const ozg_enc_entry *d_entries, ozg_enc_result *d_results, uint32_t n, void *stream) {
-	int rc = need_ready ();
+	dev_ctx *C;
+	int rc = need_ctx (&C);
 	if (rc != OZG_OK) {
 		return rc;
 	}
-	(void)src_len;
-	(void)dst_len;
 	if (n == 0) {
 		return OZG_OK;
 	}
@@ -601,17 +788,18 @@ int ozg_encode_batch_device(const void *d_src, uint64_t src_len, void *d_dst, ui
 	}
 	hipStream_t s = (hipStream_t)stream;
 	hipLaunchKernelGGL (otz_encode_kernel, dim3 (n), dim3 (64), sizeof (otz_enc_lds), s, (const u8 *)d_src, (u8 *)d_dst,
-		d_entries, d_results, n);
+		d_entries, d_results, n, (u64)src_len, (u64)dst_len);
 	OZG_HIP (hipGetLastError ());
 	hipLaunchKernelGGL (otz_enc_crc_kernel, dim3 (n), dim3 (256), sizeof (otz_copy_lds), s, (const u8 *)d_src, (u8 *)d_dst,
-		d_entries, d_results, n);
+		d_entries, d_results, n, (u64)src_len, (u64)dst_len);
 	OZG_HIP (hipGetLastError ());
 	return OZG_OK;
 }
 
 int ozg_encode_batch_host(const void *src, uint64_t src_len, void *dst, uint64_t dst_len,
 	const ozg_enc_entry *entries, ozg_enc_result *results, uint32_t n) {
-	int rc = need_ready ();
+	dev_ctx *C;
+	int rc = need_ctx (&C);
 	if (rc != OZG_OK) {
 		return rc;
 	}
@@ -625,40 +813,33 @@ int ozg_encode_batch_host(const void *src, uint64_t src_len, void *dst, uint64_t
 	for (uint32_t i = 0; i < n; i++) {
 		const ozg_enc_entry &e = entries[i];
 		const bool codec_only = (e.reserved & OZG_ENC_F_CODEC_ONLY) != 0;
-		if (e.src_off + e.src_size > src_len || (e.dst_off & 15u) || e.dst_off + e.dst_cap > dst_len || (e.dst_cap < e.src_size && !codec_only)) {
+		if (e.src_off > src_len || e.src_size > src_len - e.src_off || (e.dst_off & 15u) || e.dst_off > dst_len ||
+			e.dst_cap > dst_len - e.dst_off || (e.dst_cap < e.src_size && !codec_only)) {
 			snprintf (g_err, sizeof (g_err), "encode entry %u: offsets outside the buffers, dst_off not a multiple of 16, or dst_cap < src_size", i);
 			return OZG_E_ARG;
 		}
 	}
 	std::lock_guard<std::mutex> lk (g_mu);
-	if ((rc = grow (&g_stage.d_src, &g_stage.src_cap, src_len + 64)) != OZG_OK) {
+	staging &S = C->stage;
+	if ((rc = staging_reserve (S, src_len + 64, dst_len + 64, (size_t)n * sizeof (ozg_enc_entry), (size_t)n * sizeof (ozg_enc_result))) != OZG_OK) {
 		return rc;
 	}
-	if ((rc = grow (&g_stage.d_dst, &g_stage.dst_cap, dst_len + 64)) != OZG_OK) {
-		return rc;
-	}
-	if ((rc = grow (&g_stage.d_ent, &g_stage.ent_cap, (size_t)n * sizeof (ozg_enc_entry))) != OZG_OK) {
-		return rc;
-	}
-	if ((rc = grow (&g_stage.d_res, &g_stage.res_cap, (size_t)n * sizeof (ozg_enc_result))) != OZG_OK) {
-		return rc;
-	}
-	OZG_HIP (hipMemcpyAsync (g_stage.d_src, src, src_len, hipMemcpyHostToDevice, nullptr));
-	OZG_HIP (hipMemcpyAsync (g_stage.d_ent, entries, (size_t)n * sizeof (ozg_enc_entry), hipMemcpyHostToDevice, nullptr));
-	rc = ozg_encode_batch_device (g_stage.d_src, src_len, g_stage.d_dst, dst_len, (const ozg_enc_entry *)g_stage.d_ent,
-		(ozg_enc_result *)g_stage.d_res, n, nullptr);
+	OZG_HIP (hipMemcpyAsync (S.d_src, src, src_len, hipMemcpyHostToDevice, nullptr));
+	OZG_HIP (hipMemcpyAsync (S.d_ent, entries, (size_t)n * sizeof (ozg_enc_entry), hipMemcpyHostToDevice, nullptr));
+	rc = ozg_encode_batch_device (S.d_src, src_len, S.d_dst, dst_len, (const ozg_enc_entry *)S.d_ent, (ozg_enc_result *)S.d_res, n, nullptr);
 	if (rc != OZG_OK) {
 		return rc;
 	}
-	OZG_HIP (hipMemcpyAsync (dst, g_stage.d_dst, dst_len, hipMemcpyDeviceToHost, nullptr));
-	OZG_HIP (hipMemcpyAsync (results, g_stage.d_res, (size_t)n * sizeof (ozg_enc_result), hipMemcpyDeviceToHost, nullptr));
+	OZG_HIP (hipMemcpyAsync (dst, S.d_dst, dst_len, hipMemcpyDeviceToHost, nullptr));
+	OZG_HIP (hipMemcpyAsync (results, S.d_res, (size_t)n * sizeof (ozg_enc_result), hipMemcpyDeviceToHost, nullptr));
 	OZG_HIP (hipStreamSynchronize (nullptr));
 	return OZG_OK;
 }
 
 int ozg_crc32_batch_device(const void *d_buf, const uint64_t *d_off, const uint32_t *d_len, uint32_t *d_crc,
 	uint32_t n, void *stream) {
-	int rc = need_ready ();
+	dev_ctx *C;
+	int rc = need_ctx (&C);
 	if (rc != OZG_OK) {
 		return rc;
 	}
@@ -672,7 +853,8 @@ int ozg_crc32_batch_device(const void *d_buf, const uint64_t *d_off, const uint3
 }
 
 void *ozg_malloc(size_t bytes) {
-	if (need_ready () != OZG_OK) {
+	dev_ctx *C;
+	if (need_ctx (&C) != OZG_OK) {
 		return nullptr;
 	}
 	void *p = nullptr;
@@ -689,11 +871,12 @@ void ozg_free(void *d_ptr) {
 	}
 }
 void *ozg_malloc_pinned(size_t bytes) {
-	if (need_ready () != OZG_OK) {
+	dev_ctx *C;
+	if (need_ctx (&C) != OZG_OK) {
 		return nullptr;
 	}
 	void *p = nullptr;
-	hipError_t e = hipHostMalloc (&p, bytes ? bytes : 1, hipHostMallocDefault);
+	hipError_t e = hipHostMalloc (&p, bytes ? bytes : 1, hipHostMallocPortable); // (portable: every device of the node may copy from it)
 	if (e != hipSuccess) {
 		fail_hip ("hipHostMalloc", e);
 		return nullptr;
@@ -706,7 +889,8 @@ void ozg_free_pinned(void *h_ptr) {
 	}
 }
 int ozg_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream) {
-	int rc = need_ready ();
+	dev_ctx *C;
+	int rc = need_ctx (&C);
 	if (rc != OZG_OK) {
 		return rc;
 	}
@@ -714,7 +898,8 @@ int ozg_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream) {
 	return OZG_OK;
 }
 int ozg_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream) {
-	int rc = need_ready ();
+	dev_ctx *C;
+	int rc = need_ctx (&C);
 	if (rc != OZG_OK) {
 		return rc;
 	}
@@ -722,7 +907,8 @@ int ozg_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream) {
 	return OZG_OK;
 }
 int ozg_stream_sync(void *stream) {
-	int rc = need_ready ();
+	dev_ctx *C;
+	int rc = need_ctx (&C);
 	if (rc != OZG_OK) {
 		return rc;
 	}

@@ -6,20 +6,32 @@
  * plumbing (EOCD / central directory reader :199-396, LFH/CDH/EOCD writer
  * :1443-1590).  What is NOT here is a codec: every payload goes through the GPU.
  *
- * The one structural change is batching.  The reference decodes one entry per
- * zip_fopen_index() call; a GPU only pays off on batches, and after zip_open the
- * whole directory is known (method, sizes, CRC, offset of every entry).  So the
- * first zip_fopen_index(i) outside the cached window reads the compressed bytes
- * of a run of consecutive entries starting at i with one fread, decodes the run
- * with ONE ozg_decode_batch_host() call and keeps the outputs; the following
- * calls are served from that window.  zip_file_t keeps the reference's public
- * prefix {data,size,pos}; zip_fclose releases the window when its last reader
- * goes away.
+ * The structural change is batching, on both sides.
+ *
+ * Reading (ref otezip_extract_entry :399-684, one entry per zip_fopen_index call): after
+ * zip_open the whole directory is known, so entries are decoded a WINDOW at a time: the
+ * window's stretch of the file is read with one read() into pinned memory (the local
+ * headers are parsed from that buffer: no seek + 30-byte read per entry), the batch is
+ * submitted asynchronously (H2D, kernels, D2H on a stream of its own) and the outputs land
+ * in a pinned arena that zip_file_t.data points into.  Sequential callers get read-ahead:
+ * while they consume window k, window k+1 is already being read, copied and decoded; with
+ * several GPUs (OTEZIP_GPU_DEVICES) the windows go to the devices in turn.  The first window
+ * after a miss is small and aligned to a grid (opening one file by name decodes 64 entries,
+ * not thousands); sequential use grows the windows.  zip_file_t keeps the reference's public
+ * prefix {data,size,pos}; zip_fclose releases a window when its last reader goes away.
+ *
+ * Writing (ref zip_file_add :1079-1183, one codec call per file): zip_file_add copies the
+ * source into a pinned batch buffer and returns; the batch is compressed by ONE
+ * ozg_encode_batch_host call when it is full, when the entry is needed (stat, open, replace)
+ * or at zip_close, and the local headers + payloads are then written in index order.  Until
+ * then zip_set_file_compression changes the method the entry is actually encoded with (the
+ * libzip meaning of the call; the reference relabels bytes that are already on disk).
  */
 #define _GNU_SOURCE
 #include <otezip/zip.h>
 #include <otezip_gpu.h>
 
+#include <pthread.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -30,29 +42,63 @@
 #define MAX_FIELD_LEN (64u * 1024u - 1u)
 
 /* window limits: entries, compressed bytes, output bytes per GPU batch */
-#define WIN_MAX_ENTRIES 8192u
-#define WIN_MAX_COMP (256ull << 20)
-#define WIN_MAX_OUT (1024ull << 20)
+#define WIN_FIRST_ENTRIES 64u /* first window after a miss (a power of two: windows start on this grid) */
+#define WIN_MAX_ENTRIES 1024u /* (pinning host memory costs ~0.25 ms per MB: windows stay small enough to recycle three sets) */
+#define WIN_MAX_COMP (48ull << 20)
+#define WIN_MAX_OUT (96ull << 20)
+#define READ_THREADS 4 /* a window's stretch of the file is read by this many pread()s in parallel */
+/* Pending adds are flushed at this many source bytes / entries: the ZIP32 limits, so that in
+ * practice a batch lives until zip_close (or until one of its entries is needed) and
+ * zip_set_file_compression reaches every entry added since. */
+#define PEND_FLUSH_BYTES (3ull << 30)
+#define PEND_FLUSH_ITEMS 65535u
 
 int otezip_verify_crc = 0;
 uint64_t otezip_max_expansion_ratio = 1000ULL;
 uint64_t otezip_max_expansion_slack = 1024ULL * 1024ULL;
 int otezip_ignore_zipbomb = 0;
 
+/* pinned host memory of a window; recycled between windows (pinning is expensive) */
+struct winbuf {
+	uint8_t *src, *out;
+	ozg_result *res;
+	size_t src_cap, out_cap, res_cap;
+};
+
 struct window {
 	zip_uint64_t first, count; /* entries [first, first+count) */
-	uint8_t *out;              /* outputs, entry k at out + off[k] */
+	struct winbuf b;           /* source bytes, outputs (entry k at b.out + off[k]), batch results */
 	uint64_t *off;
-	ozg_result *res;
+	ozg_result *res;           /* per entry */
 	uint8_t *valid;            /* 0: failed the pre-checks of ref :411-446 */
-	long readers;              /* open zip_file_t that point into out */
-	int detached;              /* no longer the archive's current window */
+	uint32_t *slot;            /* position of entry k in the submitted batch */
+	ozg_job *job;              /* in flight; NULL once waited for (or nothing was submitted) */
+	int failed;
+	long readers;              /* open zip_file_t that point into b.out */
+	int detached;              /* no longer one of the archive's windows */
+	struct ozh_zip *owner;
+};
+
+struct pend_item {
+	zip_uint64_t index;
+	uint64_t off;
+	uint32_t len;
 };
 
 struct ozh_zip {
 	struct zip pub; /* MUST stay first: callers see this prefix */
-	struct window *win;
-	int gpu_ready;
+	struct window *win, *ahead; /* current window, and the one being prepared behind it */
+	zip_uint64_t last_index;
+	unsigned seq_hits;     /* consecutive opens of index, index + 1, ... */
+	zip_uint64_t grow;     /* size of the next read-ahead window */
+	uint32_t cd_ofs;       /* start of the central directory when the archive was opened */
+	int ndev, next_dev;
+	/* deferred zip_file_add: sources, in index order */
+	uint8_t *pbuf;
+	size_t pcap, pused;
+	struct pend_item *pit;
+	size_t pn, pncap;
+	int write_failed;
 };
 
 struct ozh_file {
@@ -60,18 +106,59 @@ struct ozh_file {
 	struct window *win;  /* NULL: pub.data is a private heap copy */
 };
 
-static int g_gpu_state; /* 0 untried, 1 ok, -1 failed */
+#include <time.h>
+static int g_trace = -1;
+static double trace_now(void) {
+	struct timespec ts;
+	clock_gettime (CLOCK_MONOTONIC, &ts);
+	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+/* OTEZIP_TRACE=1: one line per pipeline step on stderr (diagnostics) */
+#define TRACE(...) \
+	do { \
+		if (g_trace < 0) { \
+			g_trace = getenv ("OTEZIP_TRACE") ? 1 : 0; \
+		} \
+		if (g_trace) { \
+			fprintf (stderr, "[otezip-amd %.6f] ", trace_now ()); \
+			fprintf (stderr, __VA_ARGS__); \
+			fprintf (stderr, "\n"); \
+		} \
+	} while (0)
 
+static int g_gpu_state; /* 0 untried, 1 ok, -1 failed */
+static int g_ndev = 1, g_dev0 = 0;
+
+/* OTEZIP_GPU_DEVICE = first device (default 0), OTEZIP_GPU_DEVICES = how many consecutive
+ * devices the windows of an archive are dealt to (default 1) */
 static int gpu_up(void) {
 	if (g_gpu_state == 0) {
-		const char *dev = getenv ("OTEZIP_GPU_DEVICE");
-		int rc = ozg_init (dev ? atoi (dev) : 0);
-		if (rc != OZG_OK) {
-			fprintf (stderr, "otezip-amd: %s\n", ozg_last_error ());
-			g_gpu_state = -1;
-		} else {
-			g_gpu_state = 1;
+		TRACE ("initialising the GPU");
+		const char *dev = getenv ("OTEZIP_GPU_DEVICE"), *cnt = getenv ("OTEZIP_GPU_DEVICES");
+		g_dev0 = dev ? atoi (dev) : 0;
+		int want = cnt ? atoi (cnt) : 1, have = ozg_device_count ();
+		if (want < 1) {
+			want = 1;
 		}
+		if (have > 0 && g_dev0 + want > have) {
+			want = have > g_dev0 ? have - g_dev0 : 1;
+		}
+		g_ndev = 0;
+		for (int k = want - 1; k >= 0; k--) { /* (device g_dev0 last: it stays the current one) */
+			int rc = ozg_init (g_dev0 + k);
+			if (rc != OZG_OK) {
+				fprintf (stderr, "otezip-amd: %s\n", ozg_last_error ());
+				if (k == 0) {
+					g_gpu_state = -1;
+					return 0;
+				}
+				want = k;
+				continue;
+			}
+		}
+		g_ndev = want;
+		g_gpu_state = 1;
+		TRACE ("devices ready: %d from %d", g_ndev, g_dev0);
 	}
 	return g_gpu_state == 1;
 }
@@ -174,6 +261,7 @@ static int load_central(zip_t *za) {
 	if (pos < 0) {
 		return (int)pos;
 	}
+	((struct ozh_zip *)za)->cd_ofs = cd_ofs;
 	if (n == 0) {
 		if (cd_size != 0) {
 			return ERR_INCONS;
@@ -335,14 +423,60 @@ zip_t *zip_open_from_source(zip_source_t *src, int flags, zip_error_t *error) {
 	return za;
 }
 
+/* ------------------------------------------------------------------ windows */
+
+static void winbuf_free(struct winbuf *b) {
+	ozg_free_pinned (b->src);
+	ozg_free_pinned (b->out);
+	ozg_free_pinned (b->res);
+	memset (b, 0, sizeof (*b));
+}
+
+/* Pinned buffer sets outlive their windows and their archives: a process-wide pool (pinning
+ * is the expensive part of the whole ingest path).  Guarded by a mutex: archives may be used
+ * from different threads. */
+#define POOL_SETS 4
+static struct winbuf g_pool[POOL_SETS];
+static pthread_mutex_t g_pool_mu = PTHREAD_MUTEX_INITIALIZER;
+
 static void window_free(struct window *w) {
 	if (!w) {
 		return;
 	}
-	free (w->out);
+	if (w->job) {
+		ozg_job_wait (w->job); /* the copies still write into its buffers */
+		w->job = NULL;
+	}
+	int kept = 0;
+	pthread_mutex_lock (&g_pool_mu);
+	for (int i = 0; i < POOL_SETS; i++) {
+		if (!g_pool[i].src && !g_pool[i].out && !g_pool[i].res) {
+			g_pool[i] = w->b;
+			kept = 1;
+			break;
+		}
+	}
+	if (!kept) { /* full: keep the larger sets */
+		int small = 0;
+		for (int i = 1; i < POOL_SETS; i++) {
+			if (g_pool[i].out_cap < g_pool[small].out_cap) {
+				small = i;
+			}
+		}
+		if (g_pool[small].out_cap < w->b.out_cap) {
+			struct winbuf t = g_pool[small];
+			g_pool[small] = w->b;
+			w->b = t;
+		}
+	}
+	pthread_mutex_unlock (&g_pool_mu);
+	if (!kept) {
+		winbuf_free (&w->b);
+	}
 	free (w->off);
 	free (w->res);
 	free (w->valid);
+	free (w->slot);
 	free (w);
 }
 
@@ -355,6 +489,93 @@ static void window_detach(struct window *w) {
 	} else {
 		w->detached = 1;
 	}
+}
+
+/* pinned memory of at least the given sizes: the smallest pooled set that is large enough */
+static int winbuf_get(struct ozh_zip *z, struct winbuf *b, size_t src, size_t out, size_t res) {
+	(void)z;
+	memset (b, 0, sizeof (*b));
+	int best = -1;
+	pthread_mutex_lock (&g_pool_mu);
+	for (int i = 0; i < POOL_SETS; i++) {
+		if (g_pool[i].src_cap >= src && g_pool[i].out_cap >= out && g_pool[i].res_cap >= res &&
+			(best < 0 || g_pool[i].out_cap < g_pool[best].out_cap)) {
+			best = i;
+		}
+	}
+	if (best >= 0) {
+		*b = g_pool[best];
+		memset (&g_pool[best], 0, sizeof (g_pool[best]));
+	}
+	pthread_mutex_unlock (&g_pool_mu);
+	if (best >= 0) {
+		return 0;
+	}
+	/* none fits: sizes are rounded up so that the sets of one archive's windows are interchangeable */
+	b->src_cap = (src + (src >> 2) + ((size_t)1 << 20)) & ~(((size_t)1 << 20) - 1u);
+	b->out_cap = (out + (out >> 2) + ((size_t)1 << 20)) & ~(((size_t)1 << 20) - 1u);
+	b->res_cap = res < WIN_MAX_ENTRIES ? WIN_MAX_ENTRIES : res;
+	b->src = (uint8_t *)ozg_malloc_pinned (b->src_cap);
+	b->out = (uint8_t *)ozg_malloc_pinned (b->out_cap);
+	b->res = (ozg_result *)ozg_malloc_pinned (b->res_cap * sizeof (ozg_result));
+	if (!b->src || !b->out || !b->res) {
+		winbuf_free (b);
+		return -1;
+	}
+	return 0;
+}
+
+/* ---- parallel read of one stretch of the file (page-cache copies run at a few GB/s per thread) */
+struct pread_job {
+	int fd;
+	uint8_t *dst;
+	uint64_t off, len;
+	int ok;
+};
+static void *pread_run(void *p) {
+	struct pread_job *j = (struct pread_job *)p;
+	uint64_t done = 0;
+	j->ok = 1;
+	while (done < j->len) {
+		ssize_t r = pread (j->fd, j->dst + done, (size_t) (j->len - done), (off_t) (j->off + done));
+		if (r <= 0) {
+			j->ok = 0;
+			break;
+		}
+		done += (uint64_t)r;
+	}
+	return NULL;
+}
+static int read_span(FILE *fp, uint8_t *dst, uint64_t off, uint64_t len) {
+	const int fd = fileno (fp);
+	int nt = len >= ((uint64_t)4 << 20) ? READ_THREADS : 1;
+	struct pread_job job[READ_THREADS];
+	pthread_t th[READ_THREADS];
+	int started[READ_THREADS];
+	const uint64_t piece = ((len + (uint64_t)nt - 1u) / (uint64_t)nt + 4095u) & ~(uint64_t)4095u;
+	for (int i = 0; i < nt; i++) {
+		const uint64_t o = piece * (uint64_t)i;
+		job[i].fd = fd;
+		job[i].dst = dst + o;
+		job[i].off = off + o;
+		job[i].len = o >= len ? 0 : (len - o < piece ? len - o : piece);
+		job[i].ok = 1;
+		started[i] = 0;
+	}
+	for (int i = 1; i < nt; i++) {
+		started[i] = job[i].len && pthread_create (&th[i], NULL, pread_run, &job[i]) == 0;
+	}
+	pread_run (&job[0]);
+	int ok = job[0].ok;
+	for (int i = 1; i < nt; i++) {
+		if (started[i]) {
+			pthread_join (th[i], NULL);
+		} else if (job[i].len) {
+			pread_run (&job[i]); /* no thread: read it here */
+		}
+		ok = ok && job[i].ok;
+	}
+	return ok ? 0 : -1;
 }
 
 static void put16(uint8_t *p, uint16_t v) { otezip_write_le16 (p, v); }
@@ -385,6 +606,9 @@ static uint32_t write_lfh(FILE *fp, const struct otezip_entry *e) {
 
 static int finalize(zip_t *za) {
 	/* ref otezip.c:1240-1271, :1494-1590 */
+	if (fseek (za->fp, 0, SEEK_END) != 0) { /* (entries may have been read back since the last write) */
+		return -1;
+	}
 	long cd_ofs = ftell (za->fp);
 	if (cd_ofs < 0 || (uint64_t)cd_ofs > UINT32_MAX) {
 		return -1;
@@ -428,6 +652,8 @@ static int finalize(zip_t *za) {
 	return 0;
 }
 
+static int flush_pending(zip_t *za);
+
 int zip_close(zip_t *za) {
 	/* ref otezip.c:1273-1295 */
 	if (!za || !za->fp) {
@@ -435,22 +661,45 @@ int zip_close(zip_t *za) {
 		return -1;
 	}
 	struct ozh_zip *z = (struct ozh_zip *)za;
+	int rc = 0;
 	if (za->mode == 1) {
-		finalize (za);
+		if (flush_pending (za) != 0 || z->write_failed) {
+			rc = -1;
+		}
+		if (finalize (za) != 0) {
+			rc = -1;
+		}
 	}
-	fclose (za->fp);
+	if (fclose (za->fp) != 0 && za->mode == 1) {
+		rc = -1;
+	}
 	for (zip_uint64_t i = 0; i < za->n_entries; i++) {
 		free (za->entries[i].name);
 	}
 	free (za->entries);
+	if (z->win) {
+		z->win->owner = NULL;
+	}
+	if (z->ahead) {
+		z->ahead->owner = NULL;
+	}
 	window_detach (z->win);
+	window_detach (z->ahead);
+	ozg_free_pinned (z->pbuf);
+	free (z->pit);
 	free (z);
-	return 0;
+	return rc;
 }
 
 /* --------------------------------------------------------------- directory */
 
 static int valid(const zip_t *za) { return za != NULL && za->fp != NULL; }
+
+/* added, not yet encoded and written: adds only append, so the pending entries are the tail */
+static int is_pending(const zip_t *za, zip_uint64_t index) {
+	const struct ozh_zip *z = (const struct ozh_zip *)za;
+	return z->pn > 0 && index >= z->pit[0].index;
+}
 
 zip_uint64_t zip_get_num_files(zip_t *za) { return za ? za->n_entries : 0u; }
 
@@ -485,6 +734,9 @@ int zip_stat_index(zip_t *za, zip_uint64_t index, zip_flags_t flags, zip_stat_t 
 	if (!valid (za) || !st || index >= za->n_entries) {
 		return -1;
 	}
+	if (za->mode == 1 && is_pending (za, index) && flush_pending (za) != 0) {
+		return -1; /* (sizes and CRC of an added entry exist once its batch has been encoded) */
+	}
 	zip_stat_init (st);
 	const struct otezip_entry *e = &za->entries[index];
 	st->name = e->name;
@@ -504,8 +756,22 @@ int zip_stat(zip_t *za, const char *fname, zip_flags_t flags, zip_stat_t *st) {
 
 /* ------------------------------------------------------------------ extract */
 
-/* Decode entries [first, first+count) in one GPU batch. */
-static struct window *decode_window(zip_t *za, zip_uint64_t first) {
+/* ref otezip.c:454-462, on the host: an entry the guard rejects gets no output space and is
+ * never sent to the device (a 100-byte archive must not cost gigabytes of memory) */
+static int host_zipbomb(const struct otezip_entry *e) {
+	if (otezip_ignore_zipbomb || e->comp_size == 0) {
+		return 0;
+	}
+	return (uint64_t)e->uncomp_size > (uint64_t)e->comp_size * otezip_max_expansion_ratio + otezip_max_expansion_slack;
+}
+
+/* Start decoding entries [first, first + up to want): read their bytes, submit the batch.
+ * Returns the window with its job in flight (window_wait completes it), or NULL. */
+static struct window *window_begin_ex(zip_t *za, zip_uint64_t first, zip_uint64_t want, int packed_only) {
+	struct ozh_zip *z = (struct ozh_zip *)za;
+	if (za->mode == 1) {
+		fflush (za->fp);
+	}
 	if (fseek (za->fp, 0, SEEK_END) != 0) {
 		return NULL;
 	}
@@ -513,13 +779,13 @@ static struct window *decode_window(zip_t *za, zip_uint64_t first) {
 	if (fsl < 0) {
 		return NULL;
 	}
-	uint64_t fsz = (uint64_t)fsl;
+	const uint64_t fsz = (uint64_t)fsl;
 	/* how far does the window reach */
 	zip_uint64_t count = 0;
 	uint64_t comp = 0, out = 0;
-	while (first + count < za->n_entries && count < WIN_MAX_ENTRIES) {
+	while (first + count < za->n_entries && count < want && count < WIN_MAX_ENTRIES && !is_pending (za, first + count)) {
 		const struct otezip_entry *e = &za->entries[first + count];
-		uint64_t c = e->comp_size, o = ((uint64_t)e->uncomp_size + 15u) & ~15ull;
+		uint64_t c = e->comp_size, o = host_zipbomb (e) ? 0 : ((uint64_t)e->uncomp_size + 15u) & ~15ull;
 		if (count > 0 && (comp + c > WIN_MAX_COMP || out + o > WIN_MAX_OUT)) {
 			break;
 		}
@@ -527,69 +793,111 @@ static struct window *decode_window(zip_t *za, zip_uint64_t first) {
 		out += o;
 		count++;
 	}
+	if (count == 0) {
+		return NULL;
+	}
 	struct window *w = (struct window *)calloc (1, sizeof (*w));
 	ozg_entry *ents = (ozg_entry *)calloc (count, sizeof (ozg_entry));
-	uint64_t *data_ofs = (uint64_t *)calloc (count, sizeof (uint64_t));
-	if (!w || !ents || !data_ofs) {
-		goto fail;
+	if (!w || !ents) {
+		free (w);
+		free (ents);
+		return NULL;
 	}
+	w->owner = z;
 	w->first = first;
 	w->count = count;
 	w->off = (uint64_t *)calloc (count, sizeof (uint64_t));
 	w->res = (ozg_result *)calloc (count, sizeof (ozg_result));
 	w->valid = (uint8_t *)calloc (count, 1);
-	w->out = (uint8_t *)malloc (out + 16);
-	if (!w->off || !w->res || !w->valid || !w->out) {
+	w->slot = (uint32_t *)calloc (count, sizeof (uint32_t));
+	if (!w->off || !w->res || !w->valid || !w->slot) {
 		goto fail;
 	}
-	/* per-entry checks of ref otezip.c:411-446, and the span of file bytes to read */
-	uint64_t lo = UINT64_MAX, hi = 0, o = 0;
+	/* Entries written in index order sit back to back: then ONE read covers local headers and
+	 * payloads of the window, and the headers are parsed from the buffer.  Anything else (entries
+	 * rewritten by zip_file_replace, foreign layouts) is read entry by entry into a packed buffer. */
+	uint64_t lo = za->entries[first].local_hdr_ofs, hi;
+	int one_span = !packed_only;
+	for (zip_uint64_t k = 1; k < count && one_span; k++) {
+		one_span = za->entries[first + k].local_hdr_ofs > za->entries[first + k - 1].local_hdr_ofs;
+	}
+	if (first + count < za->n_entries && !is_pending (za, first + count)) {
+		hi = za->entries[first + count].local_hdr_ofs;
+	} else {
+		hi = za->mode == 0 && z->cd_ofs ? z->cd_ofs : fsz;
+	}
+	if (hi > fsz) {
+		hi = fsz;
+	}
+	if (one_span && (hi <= za->entries[first + count - 1].local_hdr_ofs || hi - lo > comp + count * 2048ull + (1u << 20))) {
+		one_span = 0;
+	}
+	const size_t src_need = (size_t) (one_span ? hi - lo : comp + 16u * count) + 64;
+	TRACE ("window [%llu, +%llu): %s, %llu B in, %llu B out", (unsigned long long)first, (unsigned long long)count,
+		one_span ? "one read" : "entry by entry", (unsigned long long)src_need, (unsigned long long)out);
+	if (winbuf_get (z, &w->b, src_need, (size_t)out + 64, count) != 0) {
+		fprintf (stderr, "otezip-amd: %s\n", ozg_last_error ());
+		goto fail;
+	}
+	if (one_span && read_span (za->fp, w->b.src, lo, hi - lo) != 0) {
+		goto fail;
+	}
+	TRACE ("window [%llu): bytes read", (unsigned long long)first);
+	uint32_t nb = 0;
+	uint64_t o = 0, packed = 0;
 	for (zip_uint64_t k = 0; k < count; k++) {
 		const struct otezip_entry *e = &za->entries[first + k];
 		w->off[k] = o;
-		o += ((uint64_t)e->uncomp_size + 15u) & ~15ull;
-		uint8_t lfh[30];
-		if ((uint64_t)e->local_hdr_ofs > fsz || fseek (za->fp, (long)e->local_hdr_ofs, SEEK_SET) != 0 ||
-			read_fully (za->fp, lfh, 30) != 0 || rd32 (lfh) != SIG_LFH) {
+		w->res[k].status = OZG_ST_INTERNAL;
+		if (host_zipbomb (e)) {
+			w->valid[k] = 1;
+			w->slot[k] = UINT32_MAX;
+			w->res[k].status = OZG_ST_BOMB;
 			continue;
 		}
-		uint64_t d = (uint64_t)e->local_hdr_ofs + 30u + rd16 (lfh + 26) + rd16 (lfh + 28);
-		if (d > fsz || e->comp_size > MAX_PAYLOAD || e->uncomp_size > MAX_PAYLOAD || d + e->comp_size > fsz) {
+		o += ((uint64_t)e->uncomp_size + 15u) & ~15ull;
+		/* the checks of ref otezip.c:411-446 */
+		if (e->comp_size > MAX_PAYLOAD || e->uncomp_size > MAX_PAYLOAD) {
 			continue;
+		}
+		uint8_t lfh_buf[30];
+		const uint8_t *lfh = lfh_buf;
+		if (one_span) {
+			if ((uint64_t)e->local_hdr_ofs + 30u > hi) {
+				continue;
+			}
+			lfh = w->b.src + (e->local_hdr_ofs - lo);
+		} else if ((uint64_t)e->local_hdr_ofs > fsz || fseek (za->fp, (long)e->local_hdr_ofs, SEEK_SET) != 0 ||
+			read_fully (za->fp, lfh_buf, 30) != 0) {
+			continue;
+		}
+		if (rd32 (lfh) != SIG_LFH) {
+			continue;
+		}
+		const uint64_t d = (uint64_t)e->local_hdr_ofs + 30u + rd16 (lfh + 26) + rd16 (lfh + 28);
+		if (d > fsz || d + e->comp_size > fsz) {
+			continue;
+		}
+		uint64_t src_off;
+		if (one_span) {
+			if (d + e->comp_size > hi) {
+				/* the payload reaches past the stretch that was read: take the slow road for the window */
+				free (ents);
+				window_free (w);
+				return window_begin_ex (za, first, want, 1);
+			}
+			src_off = d - lo;
+		} else {
+			if (e->comp_size && (fseek (za->fp, (long)d, SEEK_SET) != 0 || read_fully (za->fp, w->b.src + packed, e->comp_size) != 0)) {
+				continue;
+			}
+			src_off = packed;
+			packed += ((uint64_t)e->comp_size + 15u) & ~15ull;
 		}
 		w->valid[k] = 1;
-		data_ofs[k] = d;
-		if (d < lo) {
-			lo = d;
-		}
-		if (d + e->comp_size > hi) {
-			hi = d + e->comp_size;
-		}
-	}
-	if (lo == UINT64_MAX) {
-		lo = hi = 0;
-	}
-	/* entries written in index order sit back to back: one read covers the window */
-	if (hi - lo > WIN_MAX_COMP + (64ull << 20)) {
-		goto fail; /* scattered layout: not produced by any writer this library targets */
-	}
-	uint8_t *src = (uint8_t *)malloc (hi - lo + 16);
-	if (!src) {
-		goto fail;
-	}
-	if (hi > lo && (fseek (za->fp, (long)lo, SEEK_SET) != 0 || read_fully (za->fp, src, hi - lo) != 0)) {
-		free (src);
-		goto fail;
-	}
-	uint32_t nb = 0;
-	for (zip_uint64_t k = 0; k < count; k++) {
-		const struct otezip_entry *e = &za->entries[first + k];
-		w->res[k].status = OZG_ST_INTERNAL;
-		if (!w->valid[k]) {
-			continue;
-		}
+		w->slot[k] = nb;
 		ozg_entry *b = &ents[nb++];
-		b->src_off = data_ofs[k] - lo;
+		b->src_off = src_off;
 		b->dst_off = w->off[k];
 		b->comp_size = e->comp_size;
 		b->uncomp_size = e->uncomp_size;
@@ -597,31 +905,64 @@ static struct window *decode_window(zip_t *za, zip_uint64_t first) {
 		b->method = e->method;
 		b->flags = otezip_ignore_zipbomb ? OZG_EF_IGNORE_ZIPBOMB : 0;
 	}
-	ozg_limits lim = { otezip_max_expansion_ratio, otezip_max_expansion_slack };
-	ozg_set_limits (&lim);
-	ozg_result *rb = (ozg_result *)calloc (nb ? nb : 1, sizeof (ozg_result));
-	int rc = rb ? ozg_decode_batch_host (src, hi - lo + 16, w->out, out + 16, ents, rb, nb) : OZG_E_NOMEM;
-	free (src);
-	if (rc != OZG_OK) {
-		fprintf (stderr, "otezip-amd: GPU decode failed: %s\n", ozg_last_error ());
-		free (rb);
-		goto fail;
-	}
-	nb = 0;
-	for (zip_uint64_t k = 0; k < count; k++) {
-		if (w->valid[k]) {
-			w->res[k] = rb[nb++];
+	if (nb > 0) {
+		ozg_limits lim = { otezip_max_expansion_ratio, otezip_max_expansion_slack };
+		ozg_set_limits (&lim);
+		/* the devices take the windows in turn */
+		int dev = g_dev0 + (z->next_dev++ % (g_ndev > 0 ? g_ndev : 1));
+		int rc = ozg_use_device (dev);
+		if (rc == OZG_OK) {
+			rc = ozg_decode_submit (w->b.src, (one_span ? hi - lo : packed) + 16u, w->b.out, out + 16u, ents, w->b.res, nb, &w->job);
+		}
+		if (rc != OZG_OK) {
+			fprintf (stderr, "otezip-amd: GPU decode failed: %s\n", ozg_last_error ());
+			goto fail;
 		}
 	}
-	free (rb);
 	free (ents);
-	free (data_ofs);
+	TRACE ("window [%llu): submitted %u entries", (unsigned long long)first, nb);
 	return w;
 fail:
 	free (ents);
-	free (data_ofs);
+	w->owner = z;
 	window_free (w);
 	return NULL;
+}
+
+static struct window *window_begin(zip_t *za, zip_uint64_t first, zip_uint64_t want) { return window_begin_ex (za, first, want, 0); }
+
+/* the window's outputs and results are in host memory after this */
+static int window_wait(struct window *w) {
+	if (w->failed) {
+		return -1;
+	}
+	if (w->job) {
+		TRACE ("window [%llu): waiting", (unsigned long long)w->first);
+		int rc = ozg_job_wait (w->job);
+		TRACE ("window [%llu): ready", (unsigned long long)w->first);
+		w->job = NULL;
+		if (rc != OZG_OK) {
+			fprintf (stderr, "otezip-amd: GPU decode failed: %s\n", ozg_last_error ());
+			w->failed = 1;
+			return -1;
+		}
+		for (zip_uint64_t k = 0; k < w->count; k++) {
+			if (w->valid[k] && w->slot[k] != UINT32_MAX) {
+				w->res[k] = w->b.res[w->slot[k]];
+			}
+		}
+	}
+	return 0;
+}
+
+static int in_window(const struct window *w, zip_uint64_t index) { return w && index >= w->first && index < w->first + w->count; }
+
+/* forget every decoded window (the archive's bytes changed) */
+static void windows_drop(struct ozh_zip *z) {
+	window_detach (z->win);
+	window_detach (z->ahead);
+	z->win = z->ahead = NULL;
+	z->seq_hits = 0;
 }
 
 zip_file_t *zip_fopen_index(zip_t *za, zip_uint64_t index, zip_flags_t flags) {
@@ -634,14 +975,44 @@ zip_file_t *zip_fopen_index(zip_t *za, zip_uint64_t index, zip_flags_t flags) {
 	if (!gpu_up ()) {
 		return NULL; /* no device, no decoder: said so on stderr */
 	}
-	if (!z->win || index < z->win->first || index >= z->win->first + z->win->count) {
-		window_detach (z->win);
-		z->win = decode_window (za, index);
-		if (!z->win) {
-			return NULL;
+	if (za->mode == 1 && is_pending (za, index) && flush_pending (za) != 0) {
+		return NULL;
+	}
+	z->seq_hits = (z->win || z->ahead) && index == z->last_index + 1 ? z->seq_hits + 1 : 0;
+	z->last_index = index;
+	if (!in_window (z->win, index)) {
+		if (in_window (z->ahead, index)) {
+			window_detach (z->win);
+			z->win = z->ahead;
+			z->ahead = NULL;
+		} else {
+			windows_drop (z);
+			z->grow = WIN_FIRST_ENTRIES;
+			const zip_uint64_t start = index & ~(zip_uint64_t) (WIN_FIRST_ENTRIES - 1u);
+			z->win = window_begin (za, start, WIN_FIRST_ENTRIES);
+			if (!z->win && start != index) {
+				z->win = window_begin (za, index, WIN_FIRST_ENTRIES);
+			}
+			if (!z->win) {
+				z->win = window_begin (za, index, 1); /* (an odd layout: one entry at a time) */
+			}
+			if (!z->win) {
+				return NULL;
+			}
+		}
+	}
+	/* a caller that walks the archive gets the next window prepared while it uses this one */
+	if (!z->ahead && z->seq_hits >= 2) {
+		const zip_uint64_t nf = z->win->first + z->win->count;
+		if (nf < za->n_entries && !is_pending (za, nf)) {
+			z->grow = z->grow * 4u > WIN_MAX_ENTRIES ? WIN_MAX_ENTRIES : z->grow * 4u;
+			z->ahead = window_begin (za, nf, z->grow);
 		}
 	}
 	struct window *w = z->win;
+	if (window_wait (w) != 0) {
+		return NULL;
+	}
 	zip_uint64_t k = index - w->first;
 	const struct otezip_entry *e = &za->entries[index];
 	const ozg_result *r = &w->res[k];
@@ -670,7 +1041,7 @@ zip_file_t *zip_fopen_index(zip_t *za, zip_uint64_t index, zip_flags_t flags) {
 	if (!f) {
 		return NULL;
 	}
-	f->pub.data = w->out + w->off[k];
+	f->pub.data = w->b.out + w->off[k];
 	f->pub.size = e->uncomp_size;
 	f->pub.pos = 0;
 	f->win = w;
@@ -736,56 +1107,116 @@ void zip_source_free(zip_source_t *src) {
 	free (src);
 }
 
-/* otezip_compress_data (ref :788-1076) + the CRC of :1124 for one source buffer, on the GPU:
- * one ozg_encode_batch_host call returns the payload to write, the method it ended up
- * with (the reference's "not smaller -> STORE" rule is applied on the device) and the
- * CRC-32 of the input.  Methods 93/100/97 always end as STORE, exactly as in the
- * reference, whose writers for them only add bytes.  Method 14 (private RLE
- * tokens) is stored too for now: its encoder is not built yet. */
-static int store_entry(zip_t *za, struct otezip_entry *e, zip_source_t *src) {
+/* otezip_compress_data (ref :788-1076) + the CRC of :1124 for the pending sources, on the GPU:
+ * ONE ozg_encode_batch_host call returns every payload, the method each ended up with (the
+ * reference's "not smaller -> STORE" rule is applied on the device) and the CRC-32 of each
+ * input; local headers and payloads are then written in index order.  Methods 93/100/97
+ * always end as STORE, exactly as in the reference, whose writers for them only add bytes
+ * (SURVEY F9). */
+static int flush_pending(zip_t *za) {
+	struct ozh_zip *z = (struct ozh_zip *)za;
+	const size_t n = z->pn;
+	if (n == 0) {
+		return 0;
+	}
 	if (!gpu_up ()) {
+		z->write_failed = 1;
 		return -1;
 	}
-	uint32_t n = (uint32_t)src->len;
-	uint64_t cap = ozg_compress_bound (e->method, n);
-	uint8_t *out = (uint8_t *)malloc ((size_t)cap + 32);
-	uint8_t *in = (uint8_t *)malloc ((size_t)n + 32);
-	if (!out || !in) {
-		free (out);
-		free (in);
-		return -1;
+	int rc = -1;
+	ozg_enc_entry *ee = (ozg_enc_entry *)calloc (n, sizeof (*ee));
+	ozg_enc_result *er = NULL;
+	uint8_t *out = NULL;
+	uint64_t ocap = 0;
+	if (!ee) {
+		goto done;
 	}
-	if (n) {
-		memcpy (in, src->buf, n);
+	for (size_t i = 0; i < n; i++) {
+		const struct otezip_entry *e = &za->entries[z->pit[i].index];
+		ee[i].src_off = z->pit[i].off;
+		ee[i].src_size = z->pit[i].len;
+		ee[i].method = e->method; /* (what zip_set_file_compression left there) */
+		ee[i].dst_off = ocap;
+		const uint64_t cap = ozg_compress_bound (e->method, z->pit[i].len);
+		ee[i].dst_cap = (uint32_t)cap;
+		ocap += (cap + 15u) & ~15ull;
 	}
-	ozg_enc_entry ee;
-	memset (&ee, 0, sizeof (ee));
-	ee.src_size = n;
-	ee.dst_cap = (uint32_t)cap;
-	ee.method = e->method;
-	ozg_enc_result er;
-	memset (&er, 0, sizeof (er));
-	int rc = ozg_encode_batch_host (in, (uint64_t)n + 16, out, cap + 16, &ee, &er, 1);
-	free (in);
-	if (rc != OZG_OK || er.status != OZG_ST_OK) {
+	ozg_use_device (g_dev0);
+	out = (uint8_t *)ozg_malloc_pinned ((size_t)ocap + 64);
+	er = (ozg_enc_result *)ozg_malloc_pinned (n * sizeof (*er));
+	if (!out || !er) {
+		fprintf (stderr, "otezip-amd: %s\n", ozg_last_error ());
+		goto done;
+	}
+	if (ozg_encode_batch_host (z->pbuf, z->pused + 16, out, ocap + 16, ee, er, (uint32_t)n) != OZG_OK) {
 		fprintf (stderr, "otezip-amd: GPU encode failed: %s\n", ozg_last_error ());
-		free (out);
-		return -1;
+		goto done;
 	}
-	e->method = er.method;
-	e->crc32 = er.crc32;
-	e->uncomp_size = n;
-	e->comp_size = er.comp_size;
+	if (fseek (za->fp, 0, SEEK_END) != 0) {
+		goto done;
+	}
 	long pos = ftell (za->fp);
-	if (pos < 0 || (uint64_t)pos > UINT32_MAX) {
-		free (out);
-		return -1;
+	if (pos < 0) {
+		goto done;
 	}
-	e->local_hdr_ofs = (uint32_t)pos;
-	write_lfh (za->fp, e);
-	int ok = er.comp_size == 0 || fwrite (out, 1, er.comp_size, za->fp) == er.comp_size;
-	free (out);
-	return ok ? 0 : -1;
+	uint64_t at = (uint64_t)pos;
+	for (size_t i = 0; i < n; i++) {
+		struct otezip_entry *e = &za->entries[z->pit[i].index];
+		if (er[i].status != OZG_ST_OK || at > UINT32_MAX) {
+			goto done;
+		}
+		e->method = er[i].method;
+		e->crc32 = er[i].crc32;
+		e->comp_size = er[i].comp_size;
+		e->local_hdr_ofs = (uint32_t)at;
+		at += write_lfh (za->fp, e);
+		if (er[i].comp_size && fwrite (out + ee[i].dst_off, 1, er[i].comp_size, za->fp) != er[i].comp_size) {
+			goto done;
+		}
+		at += er[i].comp_size;
+	}
+	rc = 0;
+done:
+	ozg_free_pinned (out);
+	ozg_free_pinned (er);
+	free (ee);
+	z->pn = 0;
+	z->pused = 0;
+	if (rc != 0) {
+		z->write_failed = 1;
+	}
+	return rc;
+}
+
+/* room for len more source bytes in the pinned batch buffer */
+static int pending_reserve(struct ozh_zip *z, size_t len) {
+	const size_t need = z->pused + ((len + 15u) & ~(size_t)15u) + 64;
+	if (need > z->pcap) {
+		size_t cap = z->pcap ? z->pcap : (size_t)4 << 20;
+		while (cap < need) {
+			cap *= 2;
+		}
+		uint8_t *nb = (uint8_t *)ozg_malloc_pinned (cap);
+		if (!nb) {
+			return -1;
+		}
+		if (z->pused) {
+			memcpy (nb, z->pbuf, z->pused);
+		}
+		ozg_free_pinned (z->pbuf);
+		z->pbuf = nb;
+		z->pcap = cap;
+	}
+	if (z->pn == z->pncap) {
+		size_t nc = z->pncap ? 2 * z->pncap : 1024;
+		struct pend_item *ni = (struct pend_item *)realloc (z->pit, nc * sizeof (*ni));
+		if (!ni) {
+			return -1;
+		}
+		z->pit = ni;
+		z->pncap = nc;
+	}
+	return 0;
 }
 
 zip_int64_t zip_file_add(zip_t *za, const char *name, zip_source_t *src, zip_flags_t flags) {
@@ -794,9 +1225,18 @@ zip_int64_t zip_file_add(zip_t *za, const char *name, zip_source_t *src, zip_fla
 	if (!za || !name || !src || za->mode != 1) {
 		return -1;
 	}
+	struct ozh_zip *z = (struct ozh_zip *)za;
 	size_t nl = strlen (name);
 	if (nl > MAX_FIELD_LEN || src->len > MAX_PAYLOAD || src->len > UINT32_MAX) {
 		return -1;
+	}
+	if (!gpu_up ()) {
+		return -1; /* there is no CPU encoder to fall back to */
+	}
+	if (z->pn >= PEND_FLUSH_ITEMS || (z->pn && z->pused + src->len > PEND_FLUSH_BYTES)) {
+		if (flush_pending (za) != 0) {
+			return -1;
+		}
 	}
 	struct otezip_entry *ne = (struct otezip_entry *)realloc (za->entries, (za->n_entries + 1) * sizeof (*ne));
 	if (!ne) {
@@ -805,18 +1245,28 @@ zip_int64_t zip_file_add(zip_t *za, const char *name, zip_source_t *src, zip_fla
 	za->entries = ne;
 	struct otezip_entry *e = &za->entries[za->n_entries];
 	memset (e, 0, sizeof (*e));
+	if (pending_reserve (z, (size_t)src->len) != 0) {
+		return -1; /* src stays with the caller, as in the reference */
+	}
 	e->name = (char *)malloc (nl + 1);
 	if (!e->name) {
 		return -1;
 	}
 	memcpy (e->name, name, nl + 1);
-	e->method = za->default_method;
+	e->method = za->default_method > 0 ? za->default_method : 0;
+	e->uncomp_size = (uint32_t)src->len;
 	dostime_now (&e->file_time, &e->file_date);
 	e->external_attr = 0100644u << 16;
-	if (store_entry (za, e, src) != 0) {
-		free (e->name);
-		return -1; /* src stays with the caller, as in the reference */
+	/* the bytes are copied now: like the reference, the call is done with the caller's buffer
+	 * when it returns (comp_size, CRC and offset follow when the batch is encoded) */
+	struct pend_item *it = &z->pit[z->pn++];
+	it->index = za->n_entries;
+	it->off = z->pused;
+	it->len = (uint32_t)src->len;
+	if (src->len) {
+		memcpy (z->pbuf + z->pused, src->buf, (size_t)src->len);
 	}
+	z->pused += ((size_t)src->len + 15u) & ~(size_t)15u;
 	if (src->freep) {
 		free ((void *)src->buf);
 	}
@@ -829,21 +1279,48 @@ zip_int64_t zip_file_add(zip_t *za, const char *name, zip_source_t *src, zip_fla
 int zip_file_replace(zip_t *za, zip_uint64_t index, zip_source_t *src, zip_flags_t flags) {
 	/* ref otezip.c:1617-1658: a new local header + payload at the end of the file */
 	(void)flags;
-	if (!valid (za) || index >= za->n_entries || !src || za->mode != 1 || src->len > UINT32_MAX) {
+	if (!valid (za) || index >= za->n_entries || !src || za->mode != 1 || src->len > UINT32_MAX || src->len > MAX_PAYLOAD) {
 		return -1;
 	}
-	return store_entry (za, &za->entries[index], src);
+	struct ozh_zip *z = (struct ozh_zip *)za;
+	if (!gpu_up () || flush_pending (za) != 0) {
+		return -1;
+	}
+	/* the entry's new bytes: a batch of one, written at once */
+	if (pending_reserve (z, (size_t)src->len) != 0) {
+		return -1;
+	}
+	struct otezip_entry *e = &za->entries[index];
+	const struct otezip_entry keep = *e;
+	e->uncomp_size = (uint32_t)src->len; /* (the entry keeps its method, ref :1630) */
+	struct pend_item *it = &z->pit[z->pn++];
+	it->index = index;
+	it->off = 0;
+	it->len = (uint32_t)src->len;
+	if (src->len) {
+		memcpy (z->pbuf, src->buf, (size_t)src->len);
+	}
+	z->pused = ((size_t)src->len + 15u) & ~(size_t)15u;
+	if (flush_pending (za) != 0) {
+		char *nm = e->name;
+		*e = keep;
+		e->name = nm;
+		return -1;
+	}
+	windows_drop (z); /* decoded copies of the old bytes must not be served */
+	return 0;
 }
 
 int zip_replace(zip_t *za, zip_uint64_t index, zip_source_t *src) { return zip_file_replace (za, index, src, 0); }
 zip_int64_t zip_add(zip_t *za, const char *name, zip_source_t *src) { return zip_file_add (za, name, src, 0); }
 
 int zip_set_file_compression(zip_t *za, zip_uint64_t index, zip_int32_t comp, zip_uint32_t comp_flags) {
-	/* ref otezip.c:1186-1237 validates the method and then only relabels an entry
-	 * whose bytes are already on disk, which makes the archive unreadable (SURVEY
-	 * F10; the reference's own test_set_file_compression.c fails on it).  Here the
-	 * label always describes the bytes that were written, so the call validates
-	 * and succeeds without corrupting the entry. */
+	/* ref otezip.c:1186-1237 validates the method and then relabels the entry even though its
+	 * bytes are already on disk, which makes the archive unreadable (the
+	 * reference's own test_set_file_compression.c fails on it).  Here an added entry is
+	 * encoded when its batch is flushed, so until then the call does what libzip's does: it
+	 * selects the method the entry is written with.  For an entry that is already on disk
+	 * the label keeps describing the bytes; the call validates and succeeds. */
 	(void)comp_flags;
 	if (!valid (za) || index >= za->n_entries || za->mode != 1) {
 		return -1;
@@ -855,8 +1332,12 @@ int zip_set_file_compression(zip_t *za, zip_uint64_t index, zip_int32_t comp, zi
 	case OTEZIP_METHOD_LZFSE:
 	case OTEZIP_METHOD_LZMA:
 	case OTEZIP_METHOD_BROTLI:
-		return 0;
+		break;
 	default:
 		return -1;
 	}
+	if (is_pending (za, index)) {
+		za->entries[index].method = (uint16_t)comp;
+	}
+	return 0;
 }

@@ -4,12 +4,48 @@
  *   zip_roundtrip list ARCHIVE            -> "n_entries\nname method comp uncomp crc\n..."
  *   zip_roundtrip extract ARCHIVE OUTDIR  -> writes every entry to OUTDIR/<index>, prints "i size|NULL"
  *   zip_roundtrip setcomp PATH            -> the test_set_file_compression scenario; exit 0 on success
+ *   zip_roundtrip extract2 ARCHIVE OUTDIR VERIFY_CRC IGNORE_ZIPBOMB [rev]
+ *                                         -> extract with the reference's global switches set; "rev": last entry first
+ *   zip_roundtrip bench-extract ARCHIVE STRIDE
+ *                                         -> times zip_open .. zip_fopen_index/zip_fclose of every entry .. zip_close;
+ *                                            prints "i crc32 size" for every STRIDE-th entry, then "TOTAL bytes seconds"
+ *   zip_roundtrip bench-add PATH INPUT N SIZE
+ *                                         -> adds N buffers of SIZE bytes read from INPUT with default method STORE,
+ *                                            sets DEFLATE on every one, closes; prints "TOTAL bytes seconds"
+ *   zip_roundtrip replace PATH            -> append + zip_file_replace + read-back scenario; exit 0 on success
  */
+#define _POSIX_C_SOURCE 200809L
 #include <otezip/zip.h>
 
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+
+static double now_s(void) {
+	struct timespec ts;
+	clock_gettime (CLOCK_MONOTONIC, &ts);
+	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* CRC-32 of the caller's view of an entry (the test compares it with zlib's) */
+static uint32_t crc32_buf(const uint8_t *p, size_t n) {
+	static uint32_t tab[256];
+	if (!tab[1]) {
+		for (uint32_t i = 0; i < 256; i++) {
+			uint32_t c = i;
+			for (int k = 0; k < 8; k++) {
+				c = (c & 1) ? (c >> 1) ^ 0xEDB88320u : c >> 1;
+			}
+			tab[i] = c;
+		}
+	}
+	uint32_t c = 0xFFFFFFFFu;
+	for (size_t i = 0; i < n; i++) {
+		c = tab[(c ^ p[i]) & 0xFF] ^ (c >> 8);
+	}
+	return ~c;
+}
 
 static int do_list(const char *path) {
 	int err = -1;
@@ -117,6 +153,177 @@ static int do_setcomp(const char *path) {
 	return 0;
 }
 
+static int do_extract2(const char *path, const char *outdir, int verify, int ignore, int rev) {
+	otezip_verify_crc = verify;
+	otezip_ignore_zipbomb = ignore;
+	int err = -1;
+	zip_t *za = zip_open (path, ZIP_RDONLY, &err);
+	if (!za) {
+		printf ("open-failed %d\n", err);
+		return 1;
+	}
+	const zip_uint64_t n = zip_get_num_files (za);
+	for (zip_uint64_t j = 0; j < n; j++) {
+		const zip_uint64_t i = rev ? n - 1 - j : j;
+		zip_file_t *zf = zip_fopen_index (za, i, 0);
+		if (!zf) {
+			printf ("%llu NULL\n", (unsigned long long)i);
+			continue;
+		}
+		char name[4096];
+		snprintf (name, sizeof (name), "%s/%llu", outdir, (unsigned long long)i);
+		FILE *f = fopen (name, "wb");
+		fwrite (zf->data, 1, zf->size, f);
+		fclose (f);
+		printf ("%llu %u\n", (unsigned long long)i, zf->size);
+		zip_fclose (zf);
+	}
+	return zip_close (za);
+}
+
+static int do_bench_extract(const char *path, unsigned stride) {
+	const double t0 = now_s ();
+	int err = -1;
+	zip_t *za = zip_open (path, ZIP_RDONLY, &err);
+	if (!za) {
+		printf ("open-failed %d\n", err);
+		return 1;
+	}
+	const zip_uint64_t n = zip_get_num_files (za);
+	unsigned long long total = 0, touched = 0;
+	int bad = 0;
+	for (zip_uint64_t i = 0; i < n; i++) {
+		zip_file_t *zf = zip_fopen_index (za, i, 0);
+		if (!zf) {
+			bad++;
+			continue;
+		}
+		total += zf->size;
+		touched += zf->size ? zf->data[0] + zf->data[zf->size - 1] : 0; /* the caller does look at the bytes */
+		if (stride && i % stride == 0) {
+			printf ("%llu %08x %u\n", (unsigned long long)i, crc32_buf (zf->data, zf->size), zf->size);
+		}
+		zip_fclose (zf);
+	}
+	zip_close (za);
+	const double t1 = now_s ();
+	printf ("TOTAL %llu %.6f %d %llu\n", total, t1 - t0, bad, touched);
+	return bad ? 2 : 0;
+}
+
+static int do_bench_add(const char *path, const char *input, unsigned n, unsigned size) {
+	FILE *in = fopen (input, "rb");
+	if (!in) {
+		return 20;
+	}
+	uint8_t *all = (uint8_t *)malloc ((size_t)n * size);
+	if (!all || fread (all, 1, (size_t)n * size, in) != (size_t)n * size) {
+		return 21;
+	}
+	fclose (in);
+	const double t0 = now_s ();
+	int err = -1;
+	zip_t *za = zip_open (path, ZIP_CREATE | ZIP_TRUNCATE, &err);
+	if (!za) {
+		return 22;
+	}
+	za->default_method = ZIP_CM_STORE;
+	for (unsigned i = 0; i < n; i++) {
+		char name[64];
+		snprintf (name, sizeof (name), "f%05u", i);
+		zip_source_t *src = zip_source_buffer (za, all + (size_t)i * size, size, 0);
+		if (zip_file_add (za, name, src, 0) != (zip_int64_t)i) {
+			return 23;
+		}
+	}
+	for (unsigned i = 0; i < n; i++) {
+		if (zip_set_file_compression (za, i, ZIP_CM_DEFLATE, 0) != 0) {
+			return 24;
+		}
+	}
+	if (zip_close (za) != 0) {
+		return 25;
+	}
+	const double t1 = now_s ();
+	printf ("TOTAL %llu %.6f\n", (unsigned long long)n * size, t1 - t0);
+	free (all);
+	return 0;
+}
+
+/* append mode, zip_file_replace and reading an entry back in the same session */
+static int do_replace(const char *path) {
+	int err = -1;
+	zip_t *za = zip_open (path, ZIP_CREATE | ZIP_TRUNCATE, &err);
+	if (!za) {
+		return 30;
+	}
+	za->default_method = ZIP_CM_DEFLATE;
+	static char a[3000], b[5000], c[100];
+	memset (a, 'a', sizeof (a));
+	memset (b, 'b', sizeof (b));
+	memset (c, 'c', sizeof (c));
+	if (zip_file_add (za, "a", zip_source_buffer (za, a, sizeof (a), 0), 0) != 0 ||
+		zip_file_add (za, "b", zip_source_buffer (za, b, sizeof (b), 0), 0) != 1) {
+		return 31;
+	}
+	zip_stat_t st;
+	if (zip_stat_index (za, 0, 0, &st) != 0 || st.size != sizeof (a) || st.comp_size == 0 || st.comp_size >= sizeof (a)) {
+		return 32; /* stat of an added entry reports what was really written */
+	}
+	if (zip_close (za) != 0) {
+		return 33;
+	}
+	/* append */
+	za = zip_open (path, ZIP_CREATE, &err);
+	if (!za || zip_get_num_files (za) != 2) {
+		return 34;
+	}
+	za->default_method = ZIP_CM_DEFLATE;
+	if (zip_file_add (za, "c", zip_source_buffer (za, c, sizeof (c), 0), 0) != 2) {
+		return 35;
+	}
+	/* read an OLD entry, replace it, read it again: the new bytes must come back */
+	zip_file_t *zf = zip_fopen_index (za, 1, 0);
+	if (!zf || zf->size != sizeof (b) || zf->data[0] != 'b') {
+		return 36;
+	}
+	zip_fclose (zf);
+	static char b2[7000];
+	memset (b2, 'B', sizeof (b2));
+	zip_source_t *rs = zip_source_buffer (za, b2, sizeof (b2), 0);
+	if (zip_file_replace (za, 1, rs, 0) != 0) {
+		return 37;
+	}
+	zip_source_free (rs); /* replace does not consume the source (ref :1617-1658) */
+	zf = zip_fopen_index (za, 1, 0);
+	if (!zf || zf->size != sizeof (b2) || zf->data[0] != 'B' || zf->data[sizeof (b2) - 1] != 'B') {
+		return 38;
+	}
+	zip_fclose (zf);
+	zf = zip_fopen_index (za, 2, 0); /* the entry added in this session */
+	if (!zf || zf->size != sizeof (c) || zf->data[5] != 'c') {
+		return 39;
+	}
+	zip_fclose (zf);
+	if (zip_close (za) != 0) {
+		return 40;
+	}
+	za = zip_open (path, ZIP_RDONLY, &err);
+	if (!za || zip_get_num_files (za) != 3) {
+		return 41;
+	}
+	const size_t want[3] = { sizeof (a), sizeof (b2), sizeof (c) };
+	const char ch[3] = { 'a', 'B', 'c' };
+	for (int i = 2; i >= 0; i--) { /* backwards: the replaced entry lies behind the others in the file */
+		zf = zip_fopen_index (za, (zip_uint64_t)i, 0);
+		if (!zf || zf->size != want[i] || zf->data[0] != (uint8_t)ch[i] || zf->data[want[i] - 1] != (uint8_t)ch[i]) {
+			return 42 + i;
+		}
+		zip_fclose (zf);
+	}
+	return zip_close (za);
+}
+
 int main(int argc, char **argv) {
 	if (argc >= 3 && !strcmp (argv[1], "list")) {
 		return do_list (argv[2]);
@@ -126,6 +333,24 @@ int main(int argc, char **argv) {
 	}
 	if (argc >= 3 && !strcmp (argv[1], "setcomp")) {
 		return do_setcomp (argv[2]);
+	}
+	if (argc >= 6 && !strcmp (argv[1], "extract2")) {
+		return do_extract2 (argv[2], argv[3], atoi (argv[4]), atoi (argv[5]), argc >= 7 && !strcmp (argv[6], "rev"));
+	}
+	if (argc >= 4 && !strcmp (argv[1], "bench-extract")) {
+		/* optional 4th argument: repeat count (the first pass pays for creating the GPU context and for
+		 * pinning the staging buffers; later passes of the same process do not) */
+		int rc = 0;
+		for (int k = 0; k < (argc >= 5 ? atoi (argv[4]) : 1) && rc == 0; k++) {
+			rc = do_bench_extract (argv[2], (unsigned)atoi (argv[3]));
+		}
+		return rc;
+	}
+	if (argc >= 6 && !strcmp (argv[1], "bench-add")) {
+		return do_bench_add (argv[2], argv[3], (unsigned)atoi (argv[4]), (unsigned)atoi (argv[5]));
+	}
+	if (argc >= 3 && !strcmp (argv[1], "replace")) {
+		return do_replace (argv[2]);
 	}
 	return 64;
 }

@@ -134,3 +134,135 @@ def test_add_then_set_compression_then_read_back(prog, tmp_path):
         assert z.read("hello.txt") == b"A" * 4096 and z.read("empty") == b""
         assert z.getinfo("hello.txt").compress_type == zipfile.ZIP_DEFLATED   # written by the GPU encoder
         assert z.getinfo("hello.txt").compress_size < 100
+
+
+@pytest.mark.gpu
+def test_global_switches_through_the_c_api(prog, tmp_path):
+    """otezip_verify_crc = 1 turns the CRC warning into a failure (ref otezip.c:670-679);
+    otezip_ignore_zipbomb = 1 lets the guarded entry through to its codec (ref :454)."""
+    items = [it for it in golden.load_items() if not it[5]["undefined"]]
+    arc = O.craft_zip([("e%03d" % i, it[0], it[1], it[2], it[3]) for i, it in enumerate(items)])
+    p = tmp_path / "all.zip"
+    p.write_bytes(arc)
+    names = [it[5]["name"] for it in items]
+    i_crc, i_bomb = names.index("deflate_crc_mismatch"), names.index("deflate_zipbomb_guard")
+    res = {}
+    for verify, ignore in ((0, 0), (1, 0), (0, 1)):
+        out_dir = tmp_path / ("o%d%d" % (verify, ignore))
+        out_dir.mkdir()
+        rc, out, err = run(prog, "extract2", str(p), str(out_dir), str(verify), str(ignore))
+        assert rc == 0, err
+        res[(verify, ignore)] = (out.strip().split("\n"), err)
+    assert not res[(0, 0)][0][i_crc].endswith("NULL") and "CRC mismatch for" in res[(0, 0)][1]
+    assert res[(1, 0)][0][i_crc].endswith("NULL")
+    assert res[(0, 0)][0][i_bomb].endswith("NULL") and "zipbomb" in res[(0, 0)][1]
+    # with the guard off the entry reaches inflate, which fails on its truncated stream -- but not as a bomb
+    assert "zipbomb" not in res[(0, 1)][1]
+    for k in range(len(items)):
+        if k not in (i_crc, i_bomb) and not (items[k][5]["flags"] & 1):
+            assert res[(0, 0)][0][k] == res[(1, 0)][0][k] == res[(0, 1)][0][k], names[k]
+
+
+@pytest.mark.gpu
+def test_ref_strict_mimics_the_reference_false_reject(prog, tmp_path):
+    """OTEZIP_REF_STRICT=1: streams the reference's inflate rejects by mistake are refused too."""
+    import cases
+    f2 = [c for c in cases.deflate_tiny_f2(n=60)
+          if O.extract_entry(*c[:4])["verdict"] & O.V_REF_FALSE_REJECT][:5]
+    assert f2
+    arc = O.craft_zip([("f%d" % i, c[0], c[1], c[2], c[3]) for i, c in enumerate(f2)])
+    p = tmp_path / "f2.zip"
+    p.write_bytes(arc)
+    for strict in (False, True):
+        out_dir = tmp_path / ("s%d" % strict)
+        out_dir.mkdir()
+        env = dict(os.environ, OTEZIP_REF_STRICT="1") if strict else os.environ
+        q = subprocess.run([prog, "extract", str(p), str(out_dir)], capture_output=True, text=True, env=env, timeout=600)
+        lines = q.stdout.strip().split("\n")
+        assert all(line.endswith("NULL") == strict for line in lines), (strict, lines)
+
+
+@pytest.mark.gpu
+def test_replace_append_and_reverse_iteration(prog, tmp_path):
+    p = str(tmp_path / "r.zip")
+    rc, out, err = run(prog, "replace", p)
+    assert rc == 0, (rc, err)
+    with zipfile.ZipFile(p) as z:
+        assert z.read("a") == b"a" * 3000 and z.read("b") == b"B" * 7000 and z.read("c") == b"c" * 100
+    # a larger archive, last entry first: every window is a miss, every byte must still be right
+    p2 = str(tmp_path / "c1.zip")
+    want = make_config1_archive(p2)
+    out_dir = tmp_path / "rev"
+    out_dir.mkdir()
+    rc, out, err = run(prog, "extract2", p2, str(out_dir), "0", "0", "rev")
+    assert rc == 0 and "NULL" not in out, err
+    for i, data in enumerate(want):
+        assert (out_dir / str(i)).read_bytes() == data
+
+
+@pytest.mark.gpu
+def test_bulk_extract_through_the_api_full_count(prog, tmp_path):
+    """BASELINE configs[1] at its full count through the drop-in API: 10 000 x 64 KiB DEFLATE entries read
+    from disk with zip_open / zip_fopen_index / zip_fclose (pipelined windows, pinned staging).
+    Every 97th entry's bytes are checked through their CRC; the rate goes to gpurun_out/."""
+    from otezip_amd import corpus
+    arc, ents = corpus.build_archive(10000, 65536)
+    p = tmp_path / "big.zip"
+    p.write_bytes(arc)
+    rc, out, err = run(prog, "bench-extract", str(p), "97", "3")
+    assert rc == 0, err
+    lines = out.strip().split("\n")
+    totals = [l.split() for l in lines if l.startswith("TOTAL")]
+    assert len(totals) == 3
+    for total in totals:
+        assert int(total[1]) == 10000 * 65536 and int(total[3]) == 0
+    n_checked = 0
+    for line in lines:
+        if line.startswith("TOTAL"):
+            continue
+        i, crc, size = line.split()
+        assert int(crc, 16) == ents[int(i)]["crc32"] and int(size) == 65536
+        n_checked += 1
+    assert n_checked == 3 * len(range(0, 10000, 97))
+    rec = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(rec, exist_ok=True)
+    with open(os.path.join(rec, "api_extract_rate.txt"), "a") as f:
+        for k, total in enumerate(totals):
+            f.write("bench-extract 10000x65536 pass %d (%s): %.3f s, %.2f GiB/s out (zip_open..zip_close, archive in "
+                    "the page cache)\n" % (k, "cold: creates the GPU context, pins the staging buffers" if k == 0 else "warm",
+                                           float(total[2]), int(total[1]) / float(total[2]) / 2**30))
+
+
+@pytest.mark.gpu
+def test_bulk_add_with_set_file_compression_full_count(prog, tmp_path):
+    """BASELINE configs[4]: 10 000 x 64 KiB buffers through zip_file_add with default method STORE, DEFLATE
+    selected afterwards with zip_set_file_compression, one zip_close.  Python's zipfile and the GPU reader
+    must both return the inputs; every entry must be method 8."""
+    from otezip_amd import corpus
+    n, size = 10000, 65536
+    bufs = corpus.text_buffers(n, size)
+    inp = tmp_path / "in.bin"
+    with open(inp, "wb") as f:
+        for b in bufs:
+            f.write(b)
+    p = str(tmp_path / "w.zip")
+    rc, out, err = run(prog, "bench-add", p, str(inp), str(n), str(size))
+    assert rc == 0, (rc, err)
+    secs = float(out.split()[2])
+    comp_total = 0
+    with zipfile.ZipFile(p) as z:
+        infos = z.infolist()
+        assert len(infos) == n
+        for i in range(0, n, 53):
+            assert infos[i].compress_type == zipfile.ZIP_DEFLATED
+            assert z.read(infos[i]) == bufs[i], i
+        comp_total = sum(i.compress_size for i in infos)
+        assert all(i.compress_type == zipfile.ZIP_DEFLATED for i in infos)
+    rc, out2, err = run(prog, "bench-extract", p, "101")
+    assert rc == 0, err
+    for line in [l for l in out2.strip().split("\n") if not l.startswith("TOTAL")]:
+        i, crc, sz = line.split()
+        assert int(crc, 16) == zlib.crc32(bufs[int(i)]) & 0xFFFFFFFF
+    with open(os.path.join(ROOT, "gpurun_out", "api_add_rate.txt"), "a") as f:
+        f.write("bench-add %dx%d: %.3f s, %.2f GiB/s in, ratio %.3f (zip_open..zip_close incl. file write)\n" %
+                (n, size, secs, n * size / secs / 2**30, n * size / comp_total))
