@@ -12,9 +12,13 @@ separately in DESIGN.md; it is never `value`).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Multi-GPU: entries are independent, so each rank decodes its own 10 000-entry
-shard of one N x 10 000-entry job (weak scaling, no data-path collective; RCCL is
-only used for the barrier and the max-over-ranks timing).
+Multi-GPU: entries are independent, so there is no data-path collective.
+  --scaling weak (default): each rank decodes its own 10 000-entry shard of one
+      N x 10 000-entry job; RCCL carries the barrier and the max/sum reductions.
+  --scaling strong: ONE 10 000-entry archive; rank 0 builds the descriptor table,
+      broadcasts it over RCCL (the "work queue"), every rank takes its contiguous,
+      byte-balanced run of entries (otezip_amd/dist.py) and uploads only that stretch
+      of the archive; counters are all-reduced.
 """
 import argparse
 import ctypes as C
@@ -62,14 +66,27 @@ def load_shard(rank, n, size, method, cache_dir):
     return arc, ent
 
 
+def kernel_build_id():
+    """Hash of the kernel sources: a PMC summary is only reported for the build it was taken from."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "otezip_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.hip"))):
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(entries, entry_bytes, method):
-    """HBM bytes per launch of the dominant kernel from the PMC counters.  Counters cannot be read
+    """HBM bytes per launch of the DEFLATE kernels from the PMC counters.  Counters cannot be read
     from inside this process: they come from the two separate rocprofv3 --pmc passes over this very
     command that tools/pmc_traffic.py reduced to profiles/<round>/pmc_traffic.json (FETCH_SIZE x2
     + WRITE_SIZE, in KiB, as the microarchitecture guide prescribes).  None when no committed
-    summary matches the workload."""
+    summary matches the workload AND the kernel sources it was measured on."""
     import glob
     best = None
+    build = kernel_build_id()
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json"))):
         try:
             with open(f) as fh:
@@ -77,7 +94,8 @@ def pmc_traffic(entries, entry_bytes, method):
         except (OSError, ValueError):
             continue
         w = j.get("workload", {})
-        if (w.get("entries"), w.get("entry_bytes"), w.get("method")) == (entries, entry_bytes, method):
+        if (w.get("entries"), w.get("entry_bytes"), w.get("method")) == (entries, entry_bytes, method) and \
+                j.get("kernel_build_id") == build:
             best = int(j["traffic_bytes_per_launch"])
     return best
 
@@ -134,6 +152,8 @@ def main():
     ap.add_argument("--cache-dir", default=os.environ.get("OTEZIP_BENCH_CACHE", "/tmp/otezip_amd_cache"))
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo to rehearse N>1 on one GPU")
     ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --entries per GPU; strong: --entries in total, split over the ranks")
     args = ap.parse_args()
 
     from otezip_amd import dist as D
@@ -147,7 +167,8 @@ def main():
     from otezip_amd import _native as N
 
     # synthetic archive first: the generator forks workers, which must happen before HIP is up
-    arc, ent = load_shard(rank, args.entries, args.entry_size, args.method, args.cache_dir)
+    strong = args.scaling == "strong" and world > 1
+    arc, ent = load_shard(0 if strong else rank, args.entries, args.entry_size, args.method, args.cache_dir)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: otezip-amd has no CPU path")
     dev_index = 0 if args.share_device else local_rank
@@ -158,8 +179,17 @@ def main():
     oz.init(dev_index)
     L = oz.lib()
 
+    base_off = 0
+    if strong:
+        # the work queue: rank 0's descriptor table, broadcast; every rank takes its byte-balanced run
+        ent = D.broadcast_table(ent if rank == 0 else None, src=0, device=red_dev)
+        lo, hi = D.partition_by_bytes(ent[:, 2] + ent[:, 3], world)[rank]
+        ent = ent[lo:hi]
+        if len(ent):
+            base_off = int(ent[0, 1])
+            arc = arc[base_off:int(ent[-1, 1] + ent[-1, 2]) + 64]  # only this rank's stretch of the archive goes to its GPU
     n = len(ent)
-    items = [(int(m), int(off), int(cs), int(us), int(crc)) for m, off, cs, us, crc in ent]
+    items = [(int(m), int(off) - base_off, int(cs), int(us), int(crc)) for m, off, cs, us, crc in ent]
     ents, dst_len = oz.make_entries(items)
     comp_bytes = int(ent[:, 2].sum())
     out_bytes = int(ent[:, 3].sum())
@@ -217,18 +247,23 @@ def main():
         line = {
             "metric": "decompressed GiB/s, batched DEFLATE extract (zip_fopen_index path), 64 KiB entries",
             "value": round(value, 3), "unit": "GiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "configs[1]: %d x %d B enwik-style entries per GPU, zlib-6 raw DEFLATE, ratio %.2f, "
-                                   "one ZIP32 archive image resident in HBM" % (n, args.entry_size, out_bytes / comp_bytes),
+            "config": {"workload": "configs[1]: %d x %d B enwik-style entries %s, zlib-6 raw DEFLATE, ratio %.2f, "
+                                   "archive image resident in HBM" % (args.entries, args.entry_size,
+                                                                       "in ONE archive split over the GPUs" if strong else "per GPU",
+                                                                       out_bytes / max(comp_bytes, 1)),
                        "entries_per_gpu": n, "entry_bytes": args.entry_size, "method": args.method,
-                       "parallelism": "entries sharded %d-way, no data-path collective" % world,
+                       "parallelism": ("one descriptor table broadcast over RCCL, entries split %d-way by bytes" if strong else
+                                       "entries sharded %d-way") % world + ", no data-path collective",
                        "ref_false_rejects": f2},
             "roofline": {"bound": "hbm", "achieved": round(algo / kavg / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(algo / kavg / HBM_PEAK, 5),
                          "traffic": pmc_traffic(n, args.entry_size, args.method),
-                         "kernel": N.lib().ozg_kernel_name_inflate().decode() if args.method == 8 else
-                         N.lib().ozg_kernel_name_copy().decode(),
+                         "kernel": (N.lib().ozg_kernel_name_index().decode() + "+" + N.lib().ozg_kernel_name_inflate().decode())
+                         if args.method == 8 else N.lib().ozg_kernel_name_copy().decode(),
+                         "kernel_build_id": kernel_build_id(),
                          "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(kavg * 1e3, 4)},
         }
         if world == 1 and not args.no_cpu_baseline:

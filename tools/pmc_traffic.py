@@ -24,11 +24,22 @@ def mean_counter(pattern, kernel, counter):
 
 
 def main():
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_build_id
     fetch_dir, write_dir, out = sys.argv[1], sys.argv[2], sys.argv[3]
-    kernel = sys.argv[4] if len(sys.argv) > 4 else "otz_inflate_kernel"
-    f, nf = mean_counter(fetch_dir + "/*/*counter_collection.csv", kernel, "FETCH_SIZE")
-    w, nw = mean_counter(write_dir + "/*/*counter_collection.csv", kernel, "WRITE_SIZE")
-    rep = {"kernel": kernel, "launches_averaged": [nf, nw], "FETCH_SIZE_KiB_raw": f, "WRITE_SIZE_KiB": w,
+    kernels = sys.argv[4].split("+") if len(sys.argv) > 4 else ["otz_index_kernel", "otz_apply_kernel"]
+    f = w = 0.0
+    per = {}
+    nf = nw = 0
+    for kernel in kernels:  # the DEFLATE path is a pair of launches: their traffic adds up
+        fk, nf = mean_counter(fetch_dir + "/*/*counter_collection.csv", kernel, "FETCH_SIZE")
+        wk, nw = mean_counter(write_dir + "/*/*counter_collection.csv", kernel, "WRITE_SIZE")
+        per[kernel] = {"FETCH_SIZE_KiB_raw": fk, "WRITE_SIZE_KiB": wk, "traffic_bytes": (2 * fk + wk) * 1024}
+        f += fk
+        w += wk
+    rep = {"kernel": "+".join(kernels), "per_kernel": per, "kernel_build_id": kernel_build_id(),
+           "launches_averaged": [nf, nw], "FETCH_SIZE_KiB_raw": f, "WRITE_SIZE_KiB": w,
            "fetch_bytes_corrected_x2": 2 * f * 1024, "write_bytes": w * 1024,
            "traffic_bytes_per_launch": (2 * f + w) * 1024,
            "workload": {"entries": 10000, "entry_bytes": 65536, "method": 8},
