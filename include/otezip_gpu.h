@@ -125,6 +125,14 @@ int ozg_decode_batch_device_ex(const void *d_src, uint64_t src_len, void *d_dst,
 int ozg_decode_batch_host(const void *src, uint64_t src_len, void *dst, uint64_t dst_len,
 	const ozg_entry *entries, ozg_result *results, uint32_t n);
 
+/* ozg_decode_batch_host plus, for DEFLATE entries, where each stream ended: end_bits[i] = the bit
+ * position behind the final end-of-block code (status OZG_ST_OK), or behind the token that did
+ * not fit (OZG_ST_NEED_OUT: dst then holds uncomp_size bytes, as the reference's inflate leaves
+ * its buffer when it returns Z_OK); 0 otherwise and for other methods.  This is what the z_stream
+ * seam derives total_in from.  end_bits may be NULL. */
+int ozg_decode_batch_host_ex(const void *src, uint64_t src_len, void *dst, uint64_t dst_len,
+	const ozg_entry *entries, ozg_result *results, uint32_t n, uint64_t *end_bits);
+
 /* Asynchronous form of ozg_decode_batch_host for an ingest / egress pipeline: enqueues the H2D
  * copies, the kernels and the D2H copies on a stream of its own and returns at once.  h_src,
  * h_dst and h_results should come from ozg_malloc_pinned (pageable memory works, but then the

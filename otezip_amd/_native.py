@@ -71,6 +71,7 @@ ABI = {
     "ozg_decode_batch_device": (C.c_int, [_VP, _U64, _VP, _U64, _VP, _VP, _U32, _VP]),
     "ozg_decode_batch_device_ex": (C.c_int, [_VP, _U64, _VP, _U64, _VP, _VP, _U32, _VP, _U32]),
     "ozg_decode_batch_host": (C.c_int, [_VP, _U64, _VP, _U64, C.POINTER(OzgEntry), C.POINTER(OzgResult), _U32]),
+    "ozg_decode_batch_host_ex": (C.c_int, [_VP, _U64, _VP, _U64, C.POINTER(OzgEntry), C.POINTER(OzgResult), _U32, _VP]),
     "ozg_compress_bound": (C.c_uint64, [C.c_uint16, _U64]),
     "ozg_encode_batch_device": (C.c_int, [_VP, _U64, _VP, _U64, _VP, _VP, _U32, _VP]),
     "ozg_encode_batch_host": (C.c_int, [_VP, _U64, _VP, _U64, C.POINTER(OzgEncEntry), C.POINTER(OzgEncResult), _U32]),

@@ -63,7 +63,7 @@ OTZ_DEV bool otz_run_index(otz_k1_lds &L, const u8 *src, u8 *dst, const ozg_entr
 }
 
 // DEFLATE entries, second half: index -> bytes
-OTZ_DEV void otz_run_apply(otz_inflate_lds &L, const u8 *src, u8 *dst, const ozg_entry &e, ozg_result *r, const ozg_limits &lim, const otz_ix_head *head, const u8 *region, u64 *prof) {
+OTZ_DEV void otz_run_apply(otz_inflate_lds &L, const u8 *src, u8 *dst, const ozg_entry &e, ozg_result *r, const ozg_limits &lim, const otz_ix_head *head, const u8 *region, u64 *prof, u64 *end_bit = nullptr) {
 	if (e.method != OZG_METHOD_DEFLATE) {
 		return;
 	}
@@ -77,7 +77,7 @@ OTZ_DEV void otz_run_apply(otz_inflate_lds &L, const u8 *src, u8 *dst, const ozg
 	J.out = dst + e.dst_off;
 	J.out_cap = e.uncomp_size;
 	J.prof = prof;
-	otz_apply_entry (L, J, e.crc32, head, region, r);
+	otz_apply_entry (L, J, e.crc32, head, region, r, end_bit);
 }
 
 // every other method, including the unsupported ones (status OZG_ST_METHOD)

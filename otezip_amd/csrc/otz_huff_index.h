@@ -49,6 +49,8 @@ static_assert ((OTZ_IX_G & (OTZ_IX_G - 1u)) == 0, "power of two");
 
 #define OTZ_K1_NONE 0xFFFFFFFFu
 #define OTZ_X_CAP 2u // exit kind: token budget of the round used up (not an error; the block goes on)
+#define OTZ_X_TRUNC_END 5u // the input ends exactly where the next token would start: the reference's loop ends
+                           // with Z_BUF_ERROR there (:610, :821-830), while running dry INSIDE a token is Z_DATA_ERROR
 
 // Decode tables of the index kernel: 16-bit entries, 10-bit root for the literal/length code.
 // This kernel never needs a literal's value or a match's distance -- only how many bits a
@@ -521,8 +523,11 @@ OTZ_DEV u32 otz_k1_classify(const otz_k1_lds &L, const u8 *slot, u32 u, u32 e, u
 		return OTZ_X_MAKE (OTZ_X_NORMAL, u);
 	}
 	const otz_k1_tok t = otz_k1_decode (L, slot, u); // the token it stopped at
+	if (u >= limit) {
+		return OTZ_X_MAKE (OTZ_X_TRUNC_END, u);
+	}
 	if (t.kind == 2u) {
-		return OTZ_X_MAKE (u >= limit ? OTZ_X_TRUNC : OTZ_X_INVALID, u);
+		return OTZ_X_MAKE (OTZ_X_INVALID, u);
 	}
 	if (u + t.nbits > limit) {
 		return OTZ_X_MAKE (OTZ_X_TRUNC, u);
@@ -619,7 +624,7 @@ OTZ_DEV otz_k1_path otz_k1_walk(const otz_k1_lds &L, const u8 *slot, bool run, u
 
 // ------------------------------------------------------------------ the entry
 
-#define OTZ_K1_ST_NEED_OUT (-100) // internal: OZG_ST_NEED_OUT is 0
+#define OTZ_K1_ST_NEED_OUT OTZ_IX_NEED_OUT
 
 // All 64 lanes.  in/n_in: the compressed payload; out_cap: uncomp_size; out_aligned: the
 // entry's output address is 16-byte aligned; region/region_bytes: the entry's arena region
@@ -647,7 +652,7 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 	u32 flags = 0, n_blocks = 0;
 	u32 rec = 32u; // region offset of the next block record
 	u32 last_btype = 0;
-	u64 eob_abs = 0;
+	u64 eob_abs = 0, clip_abs = 0;
 	bool last_block = false, ended = false;
 	u32 prev_next_at = 0; // region offset of the previous block's `next` field (0: none)
 
@@ -900,11 +905,95 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 			const u32 room = out_cap - opos;
 			const u64 overm = otz_ballot (acc && bincl > room);
 			if (overm != 0) {
+				// Lane K's path crosses the end of the output.  The reference fills the buffer, keeps the
+				// rest of the token pending and returns Z_OK (:693-760, :805-830): index the lanes before
+				// K whole, lane K up to the token that does not fit, and say where that token is.
+				const u32 K = otz_ctz64 (overm);
+				const u32 roomK = room - otz_readlane (bincl - bytes, K); // bytes lane K may still produce
+				// lane K walks its path again (alone): u = first token that does not fit
+				u32 u = lane == K ? t : s, got = 0, ntok = 0, cross_end = 0; // (t: the lane's true start)
+				if (lane == K) {
+					for (;;) {
+						const otz_k1_tok tk = otz_k1_decode (L, slot, u);
+						if (tk.kind != 0 || got + tk.obytes > roomK) {
+							cross_end = u + tk.nbits;
+							break;
+						}
+						got += tk.obytes;
+						u += tk.nbits;
+						ntok++;
+					}
+				}
+				const u32 crossK = otz_readlane (u, K), gotK = otz_readlane (got, K), ntokK = otz_readlane (ntok, K);
+				const u32 crossEndK = otz_readlane (cross_end, K);
+				// items: lanes < K as they are; lane K: one item per OTZ_IX_G tokens of the part that fits
+				// (decoded from its start: its checkpoints belong to walks that ran past this point)
+				const u32 cntK = (ntokK + OTZ_IX_G - 1u) / OTZ_IX_G;
+				const u32 cnt2 = lane < K ? cnt : lane == K ? cntK : 0u;
+				const u32 by2 = lane < K ? bytes : lane == K ? gotK : 0u;
+				const u32 binc2 = otz_wave_scan_incl (by2), cinc2 = otz_wave_scan_incl (cnt2);
+				const u32 n_new2 = otz_readlane (cinc2, 63u);
+				if (n_items + n_new2 + 1u > items_cap) {
+					status = OTZ_IX_OVERFLOW;
+					break;
+				}
+				{
+					const u32 bit0 = (u32) ((u64) (8 * slot0) - block_bit);
+					const u32 obase = opos - block_out + binc2 - by2;
+					otz_ix_item *dst = items + n_items + (cinc2 - cnt2);
+					if (lane < K) {
+						for (u32 r = 0; r < OTZ_K1_ROWS; r++) {
+							if (r < nB_items) {
+								otz_ix_item it = rowsB[r * 64u];
+								it.bit += bit0;
+								it.out += obase;
+								dst[r] = it;
+							}
+						}
+						if (tailA) {
+							otz_ix_item it;
+							it.bit = mp + bit0;
+							it.out = obase + bytesB;
+							dst[nB_items] = it;
+						}
+						for (u32 r = 1; r < OTZ_K1_ROWS; r++) {
+							if (tailA && r >= rA0 && r < nckA) {
+								otz_ix_item it = rowsA[r * 64u];
+								it.bit += bit0;
+								it.out += obase + bytesB - offA;
+								dst[nB_items + 1u + r - rA0] = it;
+							}
+						}
+					} else if (lane == K) {
+						u32 x = t, ob = 0;
+						for (u32 k = 0; k < ntokK; k++) {
+							if ((k & (OTZ_IX_G - 1u)) == 0) {
+								otz_ix_item it;
+								it.bit = x + bit0;
+								it.out = obase + ob;
+								dst[k / OTZ_IX_G] = it;
+							}
+							const otz_k1_tok tk = otz_k1_decode (L, slot, x);
+							x += tk.nbits;
+							ob += tk.obytes;
+						}
+					}
+				}
+				n_items += n_new2;
+				opos += otz_readlane (binc2, 63u);
+				const u64 kslot_bit = (u64) (8 * ((int64_t)rb + 64 * (int64_t)K - (int64_t) (OTZ_K1_WARM / 8u)));
+				clip_abs = kslot_bit + crossK;
+				abs_bit = kslot_bit + crossEndK;
+				end_bit = (u32) (clip_abs - block_bit);
 				status = OTZ_K1_ST_NEED_OUT;
 				break;
 			}
 			if (fkind == OTZ_X_INVALID || fkind == OTZ_X_TRUNC) {
 				status = OZG_ST_DATA; // ref: Z_DATA_ERROR from get_bit / no matching code
+				break;
+			}
+			if (fkind == OTZ_X_TRUNC_END) {
+				status = OZG_ST_BUF;
 				break;
 			}
 			if (n_items + n_new + 1u > items_cap) {
@@ -960,7 +1049,7 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 				end_bit = (u32) (abs_bit - block_bit);
 			}
 		}
-		if (status != 0) {
+		if (status != 0 && status != OTZ_K1_ST_NEED_OUT) {
 			break;
 		}
 		if (lane == 0) {
@@ -983,6 +1072,9 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 		prev_next_at = rec + 28u;
 		rec += (OTZ_IX_ITEMS_OFF + 8u * (n_items + 1u) + 31u) & ~31u;
 		n_blocks++;
+		if (status != 0) {
+			break;
+		}
 		ended = last_block;
 	}
 
@@ -994,12 +1086,14 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 		}
 	}
 	if (lane == 0) {
-		head->status = status == OTZ_K1_ST_NEED_OUT ? OTZ_K1_ST_NEED_OUT : status;
+		head->status = status;
 		head->total_out = opos;
 		head->flags = flags;
 		head->n_blocks = n_blocks;
-		head->first_block = 32u;
-		head->dbg[0] = head->dbg[1] = head->dbg[2] = 0;
+		head->end_lo = (u32)abs_bit;
+		head->end_hi = (u32) (abs_bit >> 32);
+		head->clip_lo = (u32)clip_abs;
+		head->clip_hi = (u32) (clip_abs >> 32);
 	}
 	if (prof && lane == 0) {
 		for (u32 i = 0; i < 10; i++) {

@@ -29,14 +29,19 @@
 #define OTZ_IX_KIND_HUFF 1u
 #define OTZ_IX_LENS 320u     // code lengths stored per Huffman block (288 + 32)
 
-// first 32 bytes of an entry's region
+#define OTZ_IX_FIRST_BLOCK 32u  // region offset of the first block record
+#define OTZ_IX_NEED_OUT (-100)  // head.status: the stream wants more output than the entry holds (OZG_ST_NEED_OUT is 0)
+
+// one per entry (its own array, not inside the region)
 struct otz_ix_head {
-	int32_t status;  // 0: index complete, the apply kernel decodes; OTZ_IX_OVERFLOW; else the entry's final status
-	u32 total_out;   // bytes the stream produces (status 0), or bytes produced before the failure
-	u32 flags;       // OZG_F_REF_FALSE_REJECT
+	int32_t status;     // 0: index complete, the apply kernel decodes; OTZ_IX_OVERFLOW; OTZ_IX_NEED_OUT: index
+	                    // complete up to the token that does not fit; else the entry's final status
+	u32 total_out;      // bytes the indexed tokens produce
+	u32 flags;          // OZG_F_REF_FALSE_REJECT
 	u32 n_blocks;
-	u32 first_block; // region offset of the first block record
-	u32 dbg[3];
+	u32 end_lo, end_hi; // status 0: bit position behind the final end-of-block code (what the reference's
+	                    // total_in is the byte count of); OTZ_IX_NEED_OUT: behind the token that does not fit
+	u32 clip_lo, clip_hi; // OTZ_IX_NEED_OUT: bit position of that token (it belongs to the last block record)
 };
 
 // block record: header, then (Huffman blocks) OTZ_IX_LENS code-length bytes and n_items + 1 items

@@ -116,7 +116,7 @@ otz_inflate_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result 
 // silently halving the number of entries in flight.
 extern "C" __global__ void __launch_bounds__ (OTZ_NT) __attribute__ ((amdgpu_waves_per_eu (4, 4)))
 otz_apply_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *results, u32 first, u32 n, u64 src_len, u64 dst_len, ozg_limits lim,
-	const u8 *arena, const otz_region *regions, const otz_ix_head *heads, u64 *prof) {
+	const u8 *arena, const otz_region *regions, const otz_ix_head *heads, u64 *prof, u64 *end_bits) {
 	extern __shared__ __attribute__ ((aligned (16))) u8 otz_smem[];
 	const u32 i = first + blockIdx.x;
 	if (i >= n) {
@@ -131,7 +131,8 @@ otz_apply_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *r
 		otz_fail (&results[i], OZG_ST_INTERNAL);
 		return;
 	}
-	otz_run_apply (L, src, dst, e, &results[i], lim, &heads[i], arena + regions[i].off, prof ? prof + 32ull * i : nullptr);
+	otz_run_apply (L, src, dst, e, &results[i], lim, &heads[i], arena + regions[i].off, prof ? prof + 32ull * i : nullptr,
+		end_bits ? end_bits + i : nullptr);
 }
 
 extern "C" __global__ void __launch_bounds__ (256)
@@ -423,7 +424,7 @@ void ws_free(workspace &ws) {
 
 // the launches of one decode batch on stream s (device pointers); the caller holds g_mu
 int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, uint64_t dst_len, const ozg_entry *d_entries,
-	ozg_result *d_results, uint32_t n, hipStream_t s, uint32_t batch_flags) {
+	ozg_result *d_results, uint32_t n, hipStream_t s, uint32_t batch_flags, u64 *d_end_bits = nullptr) {
 	int rc;
 	if (!(batch_flags & OZG_BATCH_NO_DEFLATE)) {
 		workspace &ws = C.ws;
@@ -444,7 +445,7 @@ int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, 
 				(u64)src_len, (u64)dst_len, g_limits, ws.arena, ws.regions, ws.heads, ws.ovf, g_prof);
 			OZG_HIP (hipGetLastError ());
 			hipLaunchKernelGGL (otz_apply_kernel, dim3 (n), dim3 (OTZ_NT), sizeof (otz_inflate_lds), s, (const u8 *)d_src, (u8 *)d_dst,
-				d_entries, d_results, 0u, n, (u64)src_len, (u64)dst_len, g_limits, (const u8 *)ws.arena, ws.regions, ws.heads, g_prof);
+				d_entries, d_results, 0u, n, (u64)src_len, (u64)dst_len, g_limits, (const u8 *)ws.arena, ws.regions, ws.heads, g_prof, d_end_bits);
 			OZG_HIP (hipGetLastError ());
 		} else {
 			OZG_HIP (hipEventRecord (ws.fork, s));
@@ -458,7 +459,7 @@ int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, 
 					(u64)src_len, (u64)dst_len, g_limits, ws.arena, ws.regions, ws.heads, ws.ovf, g_prof);
 				OZG_HIP (hipGetLastError ());
 				hipLaunchKernelGGL (otz_apply_kernel, dim3 (e1 - e0), dim3 (OTZ_NT), sizeof (otz_inflate_lds), cs, (const u8 *)d_src, (u8 *)d_dst,
-					d_entries, d_results, e0, n, (u64)src_len, (u64)dst_len, g_limits, (const u8 *)ws.arena, ws.regions, ws.heads, g_prof);
+					d_entries, d_results, e0, n, (u64)src_len, (u64)dst_len, g_limits, (const u8 *)ws.arena, ws.regions, ws.heads, g_prof, d_end_bits);
 				OZG_HIP (hipGetLastError ());
 			}
 			for (int k = 0; k < 2; k++) {
@@ -634,6 +635,11 @@ int ozg_decode_batch_device(const void *d_src, uint64_t src_len, void *d_dst, ui
 
 int ozg_decode_batch_host(const void *src, uint64_t src_len, void *dst, uint64_t dst_len,
 	const ozg_entry *entries, ozg_result *results, uint32_t n) {
+	return ozg_decode_batch_host_ex (src, src_len, dst, dst_len, entries, results, n, nullptr);
+}
+
+int ozg_decode_batch_host_ex(const void *src, uint64_t src_len, void *dst, uint64_t dst_len,
+	const ozg_entry *entries, ozg_result *results, uint32_t n, uint64_t *end_bits) {
 	dev_ctx *C;
 	int rc = need_ctx (&C);
 	if (rc != OZG_OK) {
@@ -652,14 +658,23 @@ int ozg_decode_batch_host(const void *src, uint64_t src_len, void *dst, uint64_t
 	}
 	std::lock_guard<std::mutex> lk (g_mu);
 	staging &S = C->stage;
-	if ((rc = staging_reserve (S, src_len + 64, dst_len + 64, (size_t)n * sizeof (ozg_entry), (size_t)n * sizeof (ozg_result))) != OZG_OK) {
+	// (results and, behind them, the optional end positions share one staging buffer)
+	const size_t res_bytes = (size_t)n * sizeof (ozg_result);
+	if ((rc = staging_reserve (S, src_len + 64, dst_len + 64, (size_t)n * sizeof (ozg_entry), res_bytes + (size_t)n * 8u)) != OZG_OK) {
 		return rc;
+	}
+	u64 *d_end = end_bits ? (u64 *) ((u8 *)S.d_res + res_bytes) : nullptr;
+	if (d_end) {
+		OZG_HIP (hipMemsetAsync (d_end, 0, (size_t)n * 8u, nullptr));
 	}
 	OZG_HIP (hipMemcpyAsync (S.d_src, src, src_len, hipMemcpyHostToDevice, nullptr));
 	OZG_HIP (hipMemcpyAsync (S.d_ent, entries, (size_t)n * sizeof (ozg_entry), hipMemcpyHostToDevice, nullptr));
-	rc = launch_decode (*C, S.d_src, src_len, S.d_dst, dst_len, (const ozg_entry *)S.d_ent, (ozg_result *)S.d_res, n, nullptr, flags);
+	rc = launch_decode (*C, S.d_src, src_len, S.d_dst, dst_len, (const ozg_entry *)S.d_ent, (ozg_result *)S.d_res, n, nullptr, flags, d_end);
 	if (rc != OZG_OK) {
 		return rc;
+	}
+	if (d_end) {
+		OZG_HIP (hipMemcpyAsync (end_bits, d_end, (size_t)n * 8u, hipMemcpyDeviceToHost, nullptr));
 	}
 	OZG_HIP (hipMemcpyAsync (dst, S.d_dst, dst_len, hipMemcpyDeviceToHost, nullptr));
 	OZG_HIP (hipMemcpyAsync (results, S.d_res, (size_t)n * sizeof (ozg_result), hipMemcpyDeviceToHost, nullptr));

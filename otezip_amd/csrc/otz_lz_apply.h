@@ -15,7 +15,6 @@
 #include "otz_inflate.h"
 #include "otz_index.h"
 
-#define OTZ_K1_ST_NEED_OUT_HEAD (-100)
 
 // ---------------------------------------------------------------- placement
 //
@@ -247,15 +246,20 @@ OTZ_DEV void otz_resolve_list(otz_inflate_lds &L, const otz_job &J, u32 round_ba
 }
 
 // All OTZ_NT work-items.  Work-item 0 writes *res.
-OTZ_DEV void otz_apply_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_crc, const otz_ix_head *head, const u8 *region, ozg_result *res) {
+// end_bit (optional): where the stream ended, for the z_stream seam's total_in.
+OTZ_DEV void otz_apply_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_crc, const otz_ix_head *head, const u8 *region, ozg_result *res, u64 *end_bit) {
 	const u32 tid = otz_tid ();
 	const int hst = head->status;
 	if (hst == OTZ_IX_OVERFLOW) {
 		return; // the index did not fit its region: otz_inflate_kernel decodes the entry on its own
 	}
-	if (hst != 0) {
+	if (end_bit && tid == 0) {
+		*end_bit = hst == 0 || hst == OTZ_IX_NEED_OUT ? ((u64)head->end_hi << 32) | head->end_lo : 0u;
+	}
+	const bool need_out = hst == OTZ_IX_NEED_OUT && head->n_blocks != 0;
+	if (hst != 0 && !need_out) {
 		if (tid == 0) {
-			res->status = hst == OTZ_K1_ST_NEED_OUT_HEAD ? OZG_ST_NEED_OUT : hst;
+			res->status = hst == OTZ_IX_NEED_OUT ? OZG_ST_NEED_OUT : hst;
 			res->total_out = head->total_out;
 			res->crc32 = 0;
 			res->flags = 0;
@@ -277,7 +281,7 @@ OTZ_DEV void otz_apply_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_cr
 	}
 	otz_sync ();
 
-	u32 boff = head->first_block;
+	u32 boff = OTZ_IX_FIRST_BLOCK;
 	for (u32 b = 0; b < n_blocks && otz_get_status (L) == 0; b++) {
 		const otz_ix_block *blk = reinterpret_cast<const otz_ix_block *> (region + boff);
 		const u32 kind = blk->kind, n_items = blk->n_items, out_len = blk->out_len;
@@ -381,6 +385,46 @@ OTZ_DEV void otz_apply_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_cr
 	}
 	if (status == 0 && opos != head->total_out) {
 		status = OZG_ST_INTERNAL;
+	}
+	if (status == 0 && need_out) {
+		// The token at head->clip does not fit: the reference reads it, writes what fits of a match
+		// and returns Z_OK with the buffer full (ref :521-545, :805-830).  Same here: the bytes are
+		// written, the entry reports OZG_ST_NEED_OUT.  (The tables of the last block are still up.)
+		const u64 clip = ((u64)head->clip_hi << 32) | head->clip_lo;
+		const u32 byte0 = (u32) (clip >> 3);
+		otz_make_room (L, J, opos, 512u, flushed, crc_reg);
+		otz_sync ();
+		const u32 skew = otz_stage_load (L, J, byte0);
+		otz_sync ();
+		const u32 p = skew * 8u + (u32) (clip & 7u);
+		const u32 w = p >> 5;
+		const otz_tok t = otz_decode_bits (L, otz_alignbit (L.stage_w[w + 1u], L.stage_w[w], p), otz_alignbit (L.stage_w[w + 2u], L.stage_w[w + 1u], p));
+		const u32 room = J.out_cap - opos;
+		u32 n = 0;
+		if (t.kind == OTZ_K_LEN) {
+			if (t.dist > opos) {
+				status = OZG_ST_DATA;
+			} else {
+				n = t.val < room ? t.val : room;
+				if (tid == 0) {
+					for (u32 i = 0; i < n; i++) { // (byte by byte: the copy may overlap itself)
+						L.ring[OTZ_RIDX (opos + i)] = L.ring[OTZ_RIDX (opos + i - t.dist)];
+					}
+				}
+			}
+		}
+		otz_sync ();
+		if (status == 0) {
+			opos += n;
+			otz_flush (L, J, flushed, opos, crc_reg);
+			if (tid == 0) {
+				res->status = OZG_ST_NEED_OUT;
+				res->total_out = opos;
+				res->crc32 = 0;
+				res->flags = 0;
+			}
+			return;
+		}
 	}
 	if (status == 0) {
 		const u32 produced = opos;

@@ -17,11 +17,19 @@
  * calls is not supported (a second call reports Z_STREAM_END).  The only byte work on the host is
  * reading a private container's length field(s) so that the batch entry carries the exact size.
  *
+ * inflate() follows the reference in what a one-call user can see: windowBits selects raw /
+ * zlib / gzip / auto-detected framing and the header is skipped the way the reference skips it
+ * (ref deflate-dec.inc.c:361-443, :452-477, :555-584; trailers are not checked there either,
+ * SURVEY F13); at Z_STREAM_END total_in counts exactly the bytes the reference's bit reader
+ * would have loaded (the kernels report the bit position behind the final end-of-block code);
+ * a stream that produces more than avail_out returns Z_OK with the buffer FULL, input consumed
+ * up to and including the token that did not fit (ref :521-545, :693-760, :805-830).
+ *
  * Differences from the reference that a caller can observe:
- *  - total_in / next_in / avail_in: all of avail_in is reported consumed on success (the
- *    batch ABI does not return the position of the final end-of-block code);
- *  - inflate with too little output space: Z_BUF_ERROR and no output, where the reference
- *    returns Z_OK with the buffer filled (its callers treat both as failure, ref otezip.c:517);
+ *  - the call after such a Z_OK cannot resume the pending copy: it returns Z_OK again without
+ *    progress (streaming across calls is not supported; the reference's callers never do it
+ *    for archive entries, ref otezip.c:503-522);
+ *  - on an error return (Z_DATA_ERROR, Z_BUF_ERROR) nothing is consumed and nothing written;
  *  - inflate: parity rules of DESIGN.md apply (the reference's premature Z_BUF_ERROR on
  *    some valid streams is repaired; malformed input fails cleanly);
  *  - deflate: the level is ignored and the output is a VALID fixed-Huffman stream (the
@@ -36,10 +44,15 @@
 #include "../../include/otezip/zstream.h"
 #include "../../include/otezip_gpu.h"
 
+enum { OZS_WRAP_NONE, OZS_WRAP_ZLIB, OZS_WRAP_GZIP, OZS_WRAP_AUTO };
+
 struct ozs_state {
 	int decode;
 	int finished;
 	int method;
+	int wrap;        /* inflate: framing selected by windowBits */
+	int header_done;
+	int stalled;     /* inflate returned Z_OK with a full buffer: cannot be resumed */
 };
 
 static int ozs_device(void) {
@@ -73,8 +86,65 @@ static int ozs_end(z_stream *strm) {
 }
 
 int inflateInit2(z_stream *strm, int windowBits) {
-	(void)windowBits; /* raw DEFLATE, 32 KiB window, whatever is asked (ref :12-40 ignores it for raw) */
-	return ozs_init (strm, 1, OZG_METHOD_DEFLATE);
+	/* ref deflate-dec.inc.c:452-477: < 0 raw, 8..15 zlib, +16 gzip, +32 auto-detect (the window
+	 * size itself does not matter here: the kernels always keep the full 32 KiB) */
+	int rc = ozs_init (strm, 1, OZG_METHOD_DEFLATE);
+	if (rc == Z_OK) {
+		struct ozs_state *st = (struct ozs_state *)strm->state;
+		st->wrap = windowBits < 0 ? OZS_WRAP_NONE : windowBits >= 40 ? OZS_WRAP_AUTO : windowBits >= 24 ? OZS_WRAP_GZIP : OZS_WRAP_ZLIB;
+	}
+	return rc;
+}
+
+/* ref skip_gzip_header, deflate-dec.inc.c:361-417: bytes to skip, or -1 */
+static int ozs_skip_gzip(const unsigned char *buf, size_t len) {
+	if (len < 10 || buf[0] != 0x1f || buf[1] != 0x8b || buf[2] != 8) {
+		return -1;
+	}
+	const unsigned flags = buf[3];
+	size_t pos = 10;
+	if (flags & 0x04) { /* FEXTRA */
+		if (pos + 2 > len) {
+			return -1;
+		}
+		pos += 2u + (buf[pos] | ((size_t)buf[pos + 1] << 8));
+		if (pos > len) {
+			return -1;
+		}
+	}
+	for (unsigned f = 0x08; f <= 0x10; f <<= 1) { /* FNAME, FCOMMENT: zero-terminated */
+		if (flags & f) {
+			while (pos < len && buf[pos] != 0) {
+				pos++;
+			}
+			if (pos >= len) {
+				return -1;
+			}
+			pos++;
+		}
+	}
+	if (flags & 0x02) { /* FHCRC */
+		pos += 2;
+		if (pos > len) {
+			return -1;
+		}
+	}
+	return (int)pos;
+}
+
+/* ref skip_zlib_header, :420-443 */
+static int ozs_skip_zlib(const unsigned char *buf, size_t len) {
+	if (len < 2 || (buf[0] & 0x0f) != 8 || (buf[0] * 256u + buf[1]) % 31u != 0) {
+		return -1;
+	}
+	size_t pos = 2;
+	if (buf[1] & 0x20) { /* preset dictionary id */
+		pos += 4;
+		if (pos > len) {
+			return -1;
+		}
+	}
+	return (int)pos;
 }
 
 int inflateInit2_(z_stream *strm, int windowBits, const char *version, int stream_size) {
@@ -154,6 +224,25 @@ static int ozs_decode(z_stream *strm) {
 	if (st->finished) {
 		return Z_STREAM_END;
 	}
+	if (st->stalled) {
+		return Z_OK; /* the buffer was filled by the previous call; the pending rest cannot be resumed here */
+	}
+	if (st->method == OZG_METHOD_DEFLATE && !st->header_done && st->wrap != OZS_WRAP_NONE) {
+		/* ref deflate-dec.inc.c:555-584 */
+		int skip;
+		if (st->wrap == OZS_WRAP_GZIP || (st->wrap == OZS_WRAP_AUTO && strm->avail_in >= 2 && strm->next_in[0] == 0x1f && strm->next_in[1] == 0x8b)) {
+			skip = ozs_skip_gzip (strm->next_in, strm->avail_in);
+		} else {
+			skip = ozs_skip_zlib (strm->next_in, strm->avail_in);
+		}
+		if (skip < 0) {
+			return Z_DATA_ERROR;
+		}
+		strm->next_in += skip;
+		strm->avail_in -= (uInt)skip;
+		strm->total_in += (uLong)skip;
+		st->header_done = 1;
+	}
 	if (ozg_init (ozs_device ()) != OZG_OK) {
 		strm->msg = ozg_last_error ();
 		return Z_STREAM_ERROR;
@@ -184,25 +273,37 @@ static int ozs_decode(z_stream *strm) {
 	if (!out) {
 		return Z_MEM_ERROR;
 	}
-	int rc = ozg_decode_batch_host (strm->avail_in ? strm->next_in : &dummy, strm->avail_in, out, out_len, &e, &r, 1);
+	uint64_t end_bit = 0;
+	int rc = ozg_decode_batch_host_ex (strm->avail_in ? strm->next_in : &dummy, strm->avail_in, out, out_len, &e, &r, 1, &end_bit);
 	if (rc != OZG_OK) {
 		free (out);
 		strm->msg = ozg_last_error ();
 		return rc == OZG_E_NOMEM ? Z_MEM_ERROR : Z_STREAM_ERROR;
+	}
+	/* input the codec consumed: for DEFLATE the bytes the reference's bit reader would have loaded */
+	uInt used = strm->avail_in;
+	if (st->method == OZG_METHOD_DEFLATE) {
+		const uint64_t bytes = (end_bit + 7u) >> 3;
+		used = bytes < strm->avail_in ? (uInt)bytes : strm->avail_in;
 	}
 	int ret;
 	switch (r.status) {
 	case OZG_ST_OK:
 		/* end of the stream; a short DEFLATE stream leaves the rest of the buffer untouched */
 		memcpy (strm->next_out, out, r.total_out);
-		ozs_advance (strm, strm->avail_in, r.total_out);
+		ozs_advance (strm, used, r.total_out);
 		st->finished = 1;
 		ret = Z_STREAM_END;
 		break;
 	case OZG_ST_NEED_OUT:
-		/* The stream wants more than avail_out bytes.  The reference fills the buffer and
-		 * returns Z_OK; the batch path does not materialise a partial last round, so the
-		 * one-shot seam reports the buffer as too small and writes nothing. */
+		if (st->method == OZG_METHOD_DEFLATE) {
+			/* the stream wants more than avail_out bytes: buffer full, Z_OK (ref :805-830) */
+			memcpy (strm->next_out, out, r.total_out);
+			ozs_advance (strm, used, r.total_out);
+			st->stalled = strm->avail_in != 0 || r.total_out != 0;
+			ret = Z_OK;
+			break;
+		}
 		ret = Z_BUF_ERROR;
 		break;
 	case OZG_ST_DATA:

@@ -45,6 +45,7 @@ struct block_args {
 	otz_ix_head *head;
 	u8 *region;
 	u32 region_bytes;
+	u64 *end_bit;
 	const ozg_enc_entry *enc_e; // phase 3: encode kernel body
 	ozg_enc_result *enc_r;
 };
@@ -58,7 +59,7 @@ void *thread_main(void *p) {
 	} else if (a->phase == 1) {
 		otz_run_index (*(otz_k1_lds *)a->lds, a->src, a->dst, *a->e, a->lim, a->head, a->region, a->region_bytes);
 	} else if (a->phase == 2) {
-		otz_run_apply (*(otz_inflate_lds *)a->lds, a->src, a->dst, *a->e, a->r, a->lim, a->head, a->region, nullptr);
+		otz_run_apply (*(otz_inflate_lds *)a->lds, a->src, a->dst, *a->e, a->r, a->lim, a->head, a->region, nullptr, a->end_bit);
 	} else if (a->e->method == OZG_METHOD_DEFLATE) {
 		otz_run_inflate (*(otz_inflate_lds *)a->lds, a->src, a->dst, *a->e, a->r, a->lim, nullptr);
 	} else {
@@ -203,6 +204,9 @@ void run_block(u32 NT, block_args proto, size_t lds_bytes) {
 //         falls back to when an index does not fit its arena region);
 // mode 2: product path with NO arena region (forces that fallback through the real plumbing);
 // region_scale_pct (mode 0): size of the arena regions relative to otz_ix_region_bytes().
+static u64 *g_end_bits = nullptr; // optional: n words, filled by the product path (emu_set_end_bits)
+extern "C" void emu_set_end_bits(uint64_t *p) { g_end_bits = (u64 *)p; }
+
 extern "C" int emu_decode_batch_mode(const void *src, uint64_t src_len, void *dst, uint64_t dst_len,
 	const ozg_entry *entries, ozg_result *results, uint32_t n, uint64_t ratio, uint64_t slack, int mode, uint32_t region_scale_pct) {
 	(void)src_len;
@@ -230,6 +234,7 @@ extern "C" int emu_decode_batch_mode(const void *src, uint64_t src_len, void *ds
 		want &= ~(u64)255u;
 		std::vector<u8> region (want + 64, 0xA5);
 		a.head = &head;
+		a.end_bit = g_end_bits ? g_end_bits + i : nullptr;
 		a.region = region.data ();
 		a.region_bytes = (u32)want;
 		a.phase = 1;

@@ -64,3 +64,46 @@ def test_deflate_overlapping_matches_across_the_ring_end():
 def test_containers():
     items = [c for c in cases.containers() if c[2] <= 70001]
     _run(items)
+
+
+def test_stream_end_position_and_full_buffer_semantics():
+    """What the z_stream seam needs from the kernels: the exact end of the stream (the reference's
+    total_in is the number of bytes its bit reader had loaded: ref deflate-dec.inc.c:44-62), and -- when
+    the stream produces more than the buffer holds -- the buffer filled exactly as the reference leaves it
+    when it returns Z_OK (:521-545, :693-760), with total_in behind the token that did not fit."""
+    import ctypes as C
+    import random
+    from helpers import O, layout, OzgResult, emu_lib, ST_OK, ST_NEED_OUT
+    r = random.Random(11)
+    items = []
+    for d, kw in [(cases.word_text(r, 3000), {}), (cases.word_text(r, 20000), {}), (cases.small_text(r, 500), dict(strategy=2)),
+                  (b"Q" * 5000, {}), (cases.word_text(r, 4000), dict(level=0)), (cases.word_text(r, 9000), dict(flush_every=700))]:
+        c = cases.raw_deflate(d, **kw)
+        for cap in (len(d), len(d) - 1, len(d) // 2, 7, len(d) + 20, max(len(d) - 258, 1)):
+            items.append((8, c + b"trailing", cap, 0, 0))
+    src, ents, dst_len = layout(items)
+    dst = C.create_string_buffer(b"\xCD" * dst_len, dst_len)
+    res = (OzgResult * len(items))()
+    ends = (C.c_uint64 * len(items))()
+    L = emu_lib()
+    L.emu_set_end_bits(ends)
+    try:
+        L.emu_decode_batch_mode(src, len(src), dst, dst_len, ents, res, len(items), 1000, 1 << 20, 0, 100)
+    finally:
+        L.emu_set_end_bits(None)
+    n_ok = n_full = 0
+    for i, (m, comp, cap, crc, fl) in enumerate(items):
+        o, ref_out = O.codec_decode(8, comp, cap)
+        if o.verdict & O.V_NO_PARITY:
+            continue
+        out = dst.raw[ents[i].dst_off:ents[i].dst_off + cap]
+        if o.correct_ret == 1:
+            assert res[i].status == ST_OK and res[i].total_out == o.total_out and out[:o.total_out] == ref_out[:o.total_out]
+            assert (ends[i] + 7) // 8 == o.total_in, (i, ends[i], o.total_in)
+            n_ok += 1
+        elif o.correct_ret == 0:
+            assert res[i].status == ST_NEED_OUT and res[i].total_out == cap == o.total_out, (i, res[i].status, res[i].total_out)
+            assert out == ref_out[:cap]
+            assert (ends[i] + 7) // 8 == o.total_in, (i, ends[i], o.total_in)
+            n_full += 1
+    assert n_ok >= 10 and n_full >= 15

@@ -33,9 +33,9 @@ def _stream(data, out_cap):
     return s, inb, out
 
 
-def gpu_inflate(L, data, out_cap):
+def gpu_inflate(L, data, out_cap, wbits=-15):
     s, inb, out = _stream(data, out_cap)
-    assert L.inflateInit2(C.byref(s), -15) == 0
+    assert L.inflateInit2(C.byref(s), wbits) == 0
     ret = L.inflate(C.byref(s), Z_FINISH)
     tin, tout, left = s.total_in, s.total_out, s.avail_out
     again = L.inflate(C.byref(s), Z_FINISH) if ret == 1 else None
@@ -70,7 +70,7 @@ def test_seam_symbols_are_exported_and_fail_loudly_without_a_gpu():
 @pytest.mark.gpu
 def test_inflate_matches_the_oracle(gpu_lib):
     L = gpu_lib.lib()
-    n_ok = n_bad = n_short = 0
+    n_ok = n_bad = n_short = n_full = 0
     for method, comp, usize, crc, flags in cases.deflate_valid() + cases.deflate_edge() + cases.deflate_fuzz(n=40):
         if method != 8 or usize == 0:
             continue
@@ -78,18 +78,41 @@ def test_inflate_matches_the_oracle(gpu_lib):
         if r.verdict & O.V_NO_PARITY:
             continue
         ret, tin, tout, left, out, again = gpu_inflate(L, comp, usize)
-        if r.correct_ret == 1:         # Z_STREAM_END (after the F2 repair)
-            assert ret == 1 and tout == r.total_out and out[:tout] == ref_out[:tout], (len(comp), usize)
-            assert tin == len(comp) and left == usize - tout and again == 1
+        assert ret == r.correct_ret, (ret, r.correct_ret, len(comp), usize)   # the reference's code (after the F2 repair)
+        if r.correct_ret == 1:         # Z_STREAM_END
+            assert tout == r.total_out and out[:tout] == ref_out[:tout], (len(comp), usize)
+            assert tin == r.total_in and left == usize - tout and again == 1   # trailing bytes are not consumed
             assert out[tout:] == b"\xCD" * (usize - tout)      # nothing written past the stream's output
             n_ok += 1
             n_short += tout < usize
-        elif r.correct_ret == 0:       # reference: Z_OK with the buffer full; one-shot seam: buffer too small
-            assert ret == -5 and tout == 0 and out == b"\xCD" * usize
+        elif r.correct_ret == 0:       # Z_OK: the buffer is full, the token that did not fit has been read
+            assert tout == r.total_out == usize and out == ref_out[:usize] and tin == r.total_in and left == 0
+            n_full += 1
         else:
-            assert ret < 0, (ret, r.correct_ret)
             n_bad += 1
-    assert n_ok > 10 and n_bad > 5
+    assert n_ok > 10 and n_bad > 5 and n_full > 5
+
+
+@pytest.mark.gpu
+def test_inflate_honours_window_bits_like_the_reference(gpu_lib):
+    """zlib / gzip / auto-detected framing (ref deflate-dec.inc.c:452-477, :555-584): the header is
+    skipped, the trailer is left unread, total_in says so."""
+    import gzip
+    L = gpu_lib.lib()
+    data = cases.word_text(__import__("random").Random(5), 30000)
+    raw = cases.raw_deflate(data)
+    zl = zlib.compress(data, 6)
+    gz = gzip.compress(data, 6, mtime=0)
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    gz_named = b"\x1f\x8b\x08\x18" + b"\0" * 6 + b"name.txt\0" + b"a comment\0" + co.compress(data)[10:] + co.flush()
+    for wbits, blob, hdr in ((15, zl, 2), (31, gz, 10), (47, gz, 10), (47, zl, 2), (31, gz_named, 10 + 9 + 10), (-15, raw, 0)):
+        ret, tin, tout, left, out, again = gpu_inflate(L, blob, len(data) + 10, wbits)
+        assert ret == 1 and out[:tout] == data and tout == len(data), (wbits, ret)
+        r, _ = O.codec_decode(8, blob[hdr:], len(data) + 10)
+        assert tin == hdr + r.total_in, (wbits, tin, hdr, r.total_in)
+    # the wrong framing is a data error, as in the reference
+    for wbits, blob in ((31, zl), (15, gz), (47, b"\x00\x01junk")):
+        assert gpu_inflate(L, blob, 100, wbits)[0] == -3
 
 
 @pytest.mark.gpu
