@@ -990,6 +990,10 @@ zip_file_t *zip_fopen_index(zip_t *za, zip_uint64_t index, zip_flags_t flags) {
 			z->grow = WIN_FIRST_ENTRIES;
 			const zip_uint64_t start = index & ~(zip_uint64_t) (WIN_FIRST_ENTRIES - 1u);
 			z->win = window_begin (za, start, WIN_FIRST_ENTRIES);
+			if (z->win && !in_window (z->win, index)) { /* (a byte limit ended the window before the entry) */
+				window_detach (z->win);
+				z->win = NULL;
+			}
 			if (!z->win && start != index) {
 				z->win = window_begin (za, index, WIN_FIRST_ENTRIES);
 			}

@@ -125,3 +125,117 @@ def test_device_resident_api(gpu_lib):
     for i, e in enumerate(ents):
         assert res[i, 0] == ST_OK and res[i, 2] == e["crc32"]
         assert zlib.crc32(host[et[i].dst_off:et[i].dst_off + e["uncomp_size"]].tobytes()) & 0xFFFFFFFF == e["crc32"]
+
+
+def test_device_path_rejects_descriptors_outside_the_buffers(gpu_lib):
+    """A table built from an untrusted central directory must not turn into an out-of-bounds access in
+    HBM: every kernel checks src_off/comp_size/dst_off/uncomp_size against src_len/dst_len
+    (overflow-safe) and fails the entry with OZG_ST_INTERNAL; its neighbours still decode."""
+    import numpy as np
+    import torch
+    from otezip_amd import corpus, _native as N
+    arc, ents = corpus.build_archive(64, 8192, methods=(8, 0, 93, 100))
+    tab = [(e["method"], e["data_off"], e["comp_size"], e["uncomp_size"], e["crc32"]) for e in ents]
+    et, dst_len = gpu_lib.make_entries(tab)
+    bad = {3: ("src_off", len(arc) - 5), 4: ("src_off", 2**63), 5: ("comp_size", 2**32 - 1), 9: ("dst_off", dst_len),
+           10: ("dst_off", 2**64 - 16), 11: ("uncomp_size", 2**32 - 1), 17: ("dst_off", et[17].dst_off + 8),
+           18: ("src_off", 2**64 - 1), 22: ("uncomp_size", dst_len + 1)}
+    for i, (field, v) in bad.items():
+        setattr(et[i], field, v)
+    dev = torch.device("cuda", 0)
+    d_src = torch.frombuffer(bytearray(arc), dtype=torch.uint8).to(dev)
+    guard = 1 << 20
+    d_dst = torch.full((dst_len + 2 * guard,), 0xCD, dtype=torch.uint8, device=dev)
+    d_ent = torch.frombuffer(bytearray(bytes(et)), dtype=torch.uint8).to(dev)
+    d_res = torch.zeros(len(tab) * 16, dtype=torch.uint8, device=dev)
+    s = torch.cuda.current_stream()
+    N.check(gpu_lib.lib().ozg_decode_batch_device(d_src.data_ptr(), d_src.numel(), d_dst.data_ptr() + guard, dst_len,
+                                                  d_ent.data_ptr(), d_res.data_ptr(), len(tab), s.cuda_stream))
+    torch.cuda.synchronize()
+    res = np.frombuffer(d_res.cpu().numpy().tobytes(), dtype=np.int32).reshape(-1, 4)
+    host = d_dst.cpu().numpy()
+    assert (host[:guard] == 0xCD).all() and (host[guard + dst_len:] == 0xCD).all()   # nothing written outside dst
+    for i, e in enumerate(ents):
+        if i in bad:
+            assert res[i, 0] == -30, (i, bad[i], res[i, 0])   # OZG_ST_INTERNAL
+        else:
+            assert res[i, 0] == ST_OK and np.uint32(res[i, 2]) == e["crc32"], i
+    # the encode side checks its descriptors too
+    import ctypes as C
+    L = gpu_lib.lib()
+    bufs = [corpus.gen_text(i, 5000) for i in range(8)]
+    ee = (N.OzgEncEntry * 8)()
+    src = b"".join(bufs)
+    off = 0
+    for i, b in enumerate(bufs):
+        ee[i].src_off, ee[i].src_size, ee[i].method = 5000 * i, 5000, 8
+        ee[i].dst_cap = int(L.ozg_compress_bound(8, 5000))
+        ee[i].dst_off = off
+        off += (ee[i].dst_cap + 15) & ~15
+    ee[2].src_off = 2**62
+    ee[5].dst_off = off + 4096
+    d_s = torch.frombuffer(bytearray(src), dtype=torch.uint8).to(dev)
+    d_o = torch.zeros(off + 64, dtype=torch.uint8, device=dev)
+    d_e = torch.frombuffer(bytearray(bytes(ee)), dtype=torch.uint8).to(dev)
+    d_r = torch.zeros(8 * 16, dtype=torch.uint8, device=dev)
+    N.check(L.ozg_encode_batch_device(d_s.data_ptr(), len(src), d_o.data_ptr(), off, d_e.data_ptr(), d_r.data_ptr(), 8, s.cuda_stream))
+    torch.cuda.synchronize()
+    er = np.frombuffer(d_r.cpu().numpy().tobytes(), dtype=np.int32).reshape(-1, 4)
+    assert [int(x) for x in er[:, 0]] == [1, 1, -30, 1, 1, -30, 1, 1]
+
+
+def test_crc32_batch_device(gpu_lib):
+    """ozg_crc32_batch_device = otezip_crc32 (ref src/lib/crc32.inc.c:40-47) over N ranges of a device buffer."""
+    import numpy as np
+    import torch
+    from otezip_amd import _native as N
+    rng = np.random.default_rng(3)
+    buf = rng.integers(0, 256, size=3_000_000, dtype=np.uint8)
+    lens = [0, 1, 3, 15, 16, 17, 255, 4095, 4096, 4097, 65536, 1_000_003, 5]
+    offs, o = [], 7
+    for n in lens:
+        offs.append(o)
+        o += n + 11
+    dev = torch.device("cuda", 0)
+    d_buf = torch.from_numpy(buf).to(dev)
+    d_off = torch.tensor(offs, dtype=torch.int64, device=dev)
+    d_len = torch.tensor(lens, dtype=torch.int32, device=dev)
+    d_crc = torch.zeros(len(lens), dtype=torch.int32, device=dev)
+    N.check(gpu_lib.lib().ozg_crc32_batch_device(d_buf.data_ptr(), d_off.data_ptr(), d_len.data_ptr(), d_crc.data_ptr(),
+                                                len(lens), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    got = d_crc.cpu().numpy().astype(np.uint32)
+    for g, a, n in zip(got, offs, lens):
+        assert int(g) == zlib.crc32(buf[a:a + n].tobytes()) & 0xFFFFFFFF, n
+
+
+def test_config1_full_count_every_entry_byte_for_byte(gpu_lib):
+    """BASELINE configs[1] at its full count, 10 000 x 64 KiB DEFLATE: EVERY entry compared byte for byte with
+    an independent inflate (host zlib), every 250th also with the oracle."""
+    from otezip_amd import corpus
+    arc, ents = corpus.build_archive(10000, 65536)
+    tab = [(e["method"], e["data_off"], e["comp_size"], e["uncomp_size"], e["crc32"]) for e in ents]
+    b = gpu_lib.decode_batch_host(arc, tab)
+    for i, e in enumerate(ents):
+        r = b.results[i]
+        assert r.status == ST_OK and r.flags == 0 and r.crc32 == e["crc32"], i
+        comp = arc[e["data_off"]:e["data_off"] + e["comp_size"]]
+        assert b.data(i) == zlib.decompress(comp, -15), i
+        if i % 250 == 0:
+            o = O.extract_entry(8, comp, e["uncomp_size"], e["crc32"])
+            assert o["correct_rc"] == 0 and b.data(i) == o["out"]
+
+
+def test_config2_full_count_private_zstd_framing(gpu_lib):
+    """BASELINE configs[2]: 10 000 x 256 KiB entries in the private method-93 framing (2.6 GB), one GPU.
+    CRC of every entry against the directory, every 500th entry byte for byte against the oracle."""
+    from otezip_amd import corpus
+    arc, ents = corpus.build_archive(10000, 262144, methods=(93,))
+    tab = [(e["method"], e["data_off"], e["comp_size"], e["uncomp_size"], e["crc32"]) for e in ents]
+    b = gpu_lib.decode_batch_host(arc, tab)
+    for i, e in enumerate(ents):
+        r = b.results[i]
+        assert r.status == ST_OK and r.flags == 0 and r.crc32 == e["crc32"] and r.total_out == 262144, i
+        if i % 500 == 0:
+            o = O.extract_entry(93, arc[e["data_off"]:e["data_off"] + e["comp_size"]], e["uncomp_size"], e["crc32"])
+            assert o["correct_rc"] == 0 and b.data(i) == o["out"]

@@ -266,3 +266,49 @@ def test_bulk_add_with_set_file_compression_full_count(prog, tmp_path):
     with open(os.path.join(ROOT, "gpurun_out", "api_add_rate.txt"), "a") as f:
         f.write("bench-add %dx%d: %.3f s, %.2f GiB/s in, ratio %.3f (zip_open..zip_close incl. file write)\n" %
                 (n, size, secs, n * size / secs / 2**30, n * size / comp_total))
+
+
+@pytest.mark.gpu
+def test_config3_full_count_mixed_archive_through_zip_open(prog, tmp_path):
+    """BASELINE configs[3]: a 50 000-entry archive alternating the private lzfse (100) and BROT (97) framings,
+    64 KiB payloads (3.3 GB), read through zip_open / zip_fopen_index: ~50 pipelined windows.  Every 211th
+    entry is checked through its CRC; per-codec rates are recorded."""
+    from otezip_amd import corpus
+    arc, ents = corpus.build_archive(50000, 65536, methods=(100, 97))
+    p = tmp_path / "mixed.zip"
+    p.write_bytes(arc)
+    del arc
+    rc, out, err = run(prog, "bench-extract", str(p), "211", "2")
+    assert rc == 0, err
+    lines = out.strip().split("\n")
+    totals = [l.split() for l in lines if l.startswith("TOTAL")]
+    assert len(totals) == 2 and all(int(t[1]) == 50000 * 65536 and int(t[3]) == 0 for t in totals)
+    for line in lines:
+        if not line.startswith("TOTAL"):
+            i, crc, size = line.split()
+            assert int(crc, 16) == ents[int(i)]["crc32"] and int(size) == 65536
+    with open(os.path.join(ROOT, "gpurun_out", "api_extract_rate.txt"), "a") as f:
+        for k, t in enumerate(totals):
+            f.write("bench-extract 50000x65536 methods 100+97, pass %d: %.3f s, %.2f GiB/s out\n" %
+                    (k, float(t[2]), int(t[1]) / float(t[2]) / 2**30))
+
+
+@pytest.mark.gpu
+def test_entry_larger_than_a_window(prog, tmp_path):
+    """One STORE entry of 60 MB (beyond the 48 MB a window normally reads) between small ones: it gets a
+    window of its own (the reference accepts entries up to 2 GiB, ref otezip.c:102)."""
+    import random
+    r = random.Random(9)
+    big = bytes(r.getrandbits(8) for _ in range(1 << 16)) * 960   # 60 MiB
+    p = str(tmp_path / "big.zip")
+    with zipfile.ZipFile(p, "w") as z:
+        z.writestr("small0", b"x" * 1000, compress_type=zipfile.ZIP_DEFLATED)
+        z.writestr("big", big, compress_type=zipfile.ZIP_STORED)
+        z.writestr("small1", b"y" * 3000, compress_type=zipfile.ZIP_DEFLATED)
+    rc, out, err = run(prog, "bench-extract", p, "1")
+    assert rc == 0, err
+    lines = out.strip().split("\n")
+    want = [b"x" * 1000, big, b"y" * 3000]
+    for line, data in zip(lines, want):
+        i, crc, size = line.split()
+        assert int(size) == len(data) and int(crc, 16) == zlib.crc32(data) & 0xFFFFFFFF
