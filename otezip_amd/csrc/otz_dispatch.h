@@ -55,11 +55,12 @@ OTZ_DEV void otz_run_inflate(otz_inflate_lds &L, const u8 *src, u8 *dst, const o
 // DEFLATE entries, first half: the index (one wavefront).  Entries the expansion guard
 // rejects get no index; the apply kernel reports them.
 // Returns true when the entry has to take the self-contained routine (index overflow).
+template <bool PROF = false>
 OTZ_DEV bool otz_run_index(otz_k1_lds &L, const u8 *src, u8 *dst, const ozg_entry &e, const ozg_limits &lim, otz_ix_head *head, u8 *region, u32 region_bytes, u64 *prof = nullptr) {
 	if (e.method != OZG_METHOD_DEFLATE || otz_zipbomb (e, lim)) {
 		return false;
 	}
-	return otz_index_entry (L, src + e.src_off, e.comp_size, e.uncomp_size, ((uintptr_t) (dst + e.dst_off) & 15u) == 0, region, region_bytes, head, prof);
+	return otz_index_entry<PROF> (L, src + e.src_off, e.comp_size, e.uncomp_size, ((uintptr_t) (dst + e.dst_off) & 15u) == 0, region, region_bytes, head, prof);
 }
 
 // DEFLATE entries, second half: index -> bytes

@@ -33,7 +33,9 @@
 #include "otz_inflate.h"
 #include "otz_index.h"
 
+#ifndef OTZ_K1_S
 #define OTZ_K1_S 512u     // segment bits per lane per round
+#endif
 #ifndef OTZ_K1_WARM
 #define OTZ_K1_WARM 128u  // head start of walk A (bits)
 #endif
@@ -63,8 +65,12 @@ static_assert ((OTZ_IX_G & (OTZ_IX_G - 1u)) == 0, "power of two");
 //           bit 15: link ([3:0] index width, [14:4] sub-table start - root size)
 #define OTZ_K1_LROOT 10u
 #define OTZ_K1_DROOT 8u
+#ifndef OTZ_K1_LLUT
 #define OTZ_K1_LLUT 1344u // 1024 + 320 (zlib's ENOUGH for 286 symbols, root 10, 15 bits: 1332)
+#endif
+#ifndef OTZ_K1_DLUT
 #define OTZ_K1_DLUT 640u  // 256 + 384
+#endif
 
 struct otz_k1_lds {
 	u16 lit[OTZ_K1_LLUT];
@@ -632,18 +638,27 @@ OTZ_DEV otz_k1_path otz_k1_walk(const otz_k1_lds &L, const u8 *slot, bool run, u
 // Returns true when the index did not fit (head->status = OTZ_IX_OVERFLOW).
 // prof: optional 16 x u64 diagnostic cycle counters (0 header+lengths, 1 tables, 2 slot load, 3 walk A,
 // 4 fixpoint, 5 accept+items, 6 rounds, 7 fixpoint iterations, 8 re-walks, 9 blocks, 15 total)
+// (PROF is a compile-time switch: the counters would otherwise occupy two dozen scalar registers
+// of the product kernel)
 #define OTZ_K1_MARK(i) \
 	do { \
-		if (prof) { \
+		if (PROF) { \
 			const u64 _t = otz_cycles (); \
 			pc[i] += _t - plast; \
 			plast = _t; \
 		} \
 	} while (0)
+#define OTZ_K1_COUNT(i) \
+	do { \
+		if (PROF) { \
+			pc[i] += 1; \
+		} \
+	} while (0)
+template <bool PROF>
 OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap, bool out_aligned, u8 *region, u32 region_bytes, otz_ix_head *head, u64 *prof = nullptr) {
 	const u32 lane = otz_lane ();
 	u64 pc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-	u64 plast = otz_cycles ();
+	u64 plast = PROF ? otz_cycles () : 0;
 	const u64 pstart = plast;
 	const u64 total_bits = (u64)n_in * 8u;
 	u64 abs_bit = 0;
@@ -700,7 +715,7 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 		last_block = H.bfinal != 0;
 		last_btype = H.btype;
 		abs_bit += H.bits;
-		pc[9] += 1;
+		OTZ_K1_COUNT (9);
 		if (rec + 32u > rec_limit) {
 			status = OTZ_IX_OVERFLOW;
 			break;
@@ -791,7 +806,7 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 		const u32 block_out = opos;
 		u32 n_items = 0;
 		u32 end_bit = 0; // block-relative position that closes the item list
-		bool block_done = false;
+		bool block_done = false, serial_finish = false;
 
 		// ---- rounds
 		while (!block_done && status == 0) {
@@ -820,7 +835,7 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 			const int64_t lb = (int64_t)total_bits - 8 * slot0; // the input ends at this slot-relative bit
 			const u32 limit = lb <= 0 ? 0u : lb > 0xFFFFFF ? 0xFFFFFFu : (u32)lb;
 			OTZ_K1_MARK (2);
-			pc[6] += 1;
+			OTZ_K1_COUNT (6);
 			// ---- walk A
 			const otz_k1_path A = otz_k1_walk<true> (L, slot, true, lane ? s - OTZ_K1_WARM : s, s, e, limit, rowsA, rowsA, 0, 0);
 			const u32 nckA = (A.n + OTZ_IX_G - 1u) / OTZ_IX_G; // checkpoint rows in front of tokens walk A took
@@ -842,9 +857,9 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 				t = lane ? nt : t;
 				const bool rewalk = moved && nt != A.first;
 				const u32 old_exit = exit_cur;
-				pc[7] += 1;
+				OTZ_K1_COUNT (7);
 				if (otz_ballot (rewalk) != 0) {
-					pc[8] += 1;
+					OTZ_K1_COUNT (8);
 					const otz_k1_path W = otz_k1_walk<false> (L, slot, rewalk, nt, s, e, limit, rowsB, rowsA, A.bm, nckA);
 #ifdef OTZ_K1_STATS
 					if (rewalk) {
@@ -905,87 +920,10 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 			const u32 room = out_cap - opos;
 			const u64 overm = otz_ballot (acc && bincl > room);
 			if (overm != 0) {
-				// Lane K's path crosses the end of the output.  The reference fills the buffer, keeps the
-				// rest of the token pending and returns Z_OK (:693-760, :805-830): index the lanes before
-				// K whole, lane K up to the token that does not fit, and say where that token is.
-				const u32 K = otz_ctz64 (overm);
-				const u32 roomK = room - otz_readlane (bincl - bytes, K); // bytes lane K may still produce
-				// lane K walks its path again (alone): u = first token that does not fit
-				u32 u = lane == K ? t : s, got = 0, ntok = 0, cross_end = 0; // (t: the lane's true start)
-				if (lane == K) {
-					for (;;) {
-						const otz_k1_tok tk = otz_k1_decode (L, slot, u);
-						if (tk.kind != 0 || got + tk.obytes > roomK) {
-							cross_end = u + tk.nbits;
-							break;
-						}
-						got += tk.obytes;
-						u += tk.nbits;
-						ntok++;
-					}
-				}
-				const u32 crossK = otz_readlane (u, K), gotK = otz_readlane (got, K), ntokK = otz_readlane (ntok, K);
-				const u32 crossEndK = otz_readlane (cross_end, K);
-				// items: lanes < K as they are; lane K: one item per OTZ_IX_G tokens of the part that fits
-				// (decoded from its start: its checkpoints belong to walks that ran past this point)
-				const u32 cntK = (ntokK + OTZ_IX_G - 1u) / OTZ_IX_G;
-				const u32 cnt2 = lane < K ? cnt : lane == K ? cntK : 0u;
-				const u32 by2 = lane < K ? bytes : lane == K ? gotK : 0u;
-				const u32 binc2 = otz_wave_scan_incl (by2), cinc2 = otz_wave_scan_incl (cnt2);
-				const u32 n_new2 = otz_readlane (cinc2, 63u);
-				if (n_items + n_new2 + 1u > items_cap) {
-					status = OTZ_IX_OVERFLOW;
-					break;
-				}
-				{
-					const u32 bit0 = (u32) ((u64) (8 * slot0) - block_bit);
-					const u32 obase = opos - block_out + binc2 - by2;
-					otz_ix_item *dst = items + n_items + (cinc2 - cnt2);
-					if (lane < K) {
-						for (u32 r = 0; r < OTZ_K1_ROWS; r++) {
-							if (r < nB_items) {
-								otz_ix_item it = rowsB[r * 64u];
-								it.bit += bit0;
-								it.out += obase;
-								dst[r] = it;
-							}
-						}
-						if (tailA) {
-							otz_ix_item it;
-							it.bit = mp + bit0;
-							it.out = obase + bytesB;
-							dst[nB_items] = it;
-						}
-						for (u32 r = 1; r < OTZ_K1_ROWS; r++) {
-							if (tailA && r >= rA0 && r < nckA) {
-								otz_ix_item it = rowsA[r * 64u];
-								it.bit += bit0;
-								it.out += obase + bytesB - offA;
-								dst[nB_items + 1u + r - rA0] = it;
-							}
-						}
-					} else if (lane == K) {
-						u32 x = t, ob = 0;
-						for (u32 k = 0; k < ntokK; k++) {
-							if ((k & (OTZ_IX_G - 1u)) == 0) {
-								otz_ix_item it;
-								it.bit = x + bit0;
-								it.out = obase + ob;
-								dst[k / OTZ_IX_G] = it;
-							}
-							const otz_k1_tok tk = otz_k1_decode (L, slot, x);
-							x += tk.nbits;
-							ob += tk.obytes;
-						}
-					}
-				}
-				n_items += n_new2;
-				opos += otz_readlane (binc2, 63u);
-				const u64 kslot_bit = (u64) (8 * ((int64_t)rb + 64 * (int64_t)K - (int64_t) (OTZ_K1_WARM / 8u)));
-				clip_abs = kslot_bit + crossK;
-				abs_bit = kslot_bit + crossEndK;
-				end_bit = (u32) (clip_abs - block_bit);
-				status = OTZ_K1_ST_NEED_OUT;
+				// A lane's path crosses the end of the output.  The reference fills the buffer, keeps the
+				// rest of the token pending and returns Z_OK (:693-760, :805-830).  The round is indexed
+				// again, token by token, below (cold path: nothing of this round's state is needed there).
+				serial_finish = true;
 				break;
 			}
 			if (fkind == OTZ_X_INVALID || fkind == OTZ_X_TRUNC) {
@@ -1049,6 +987,63 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 				end_bit = (u32) (abs_bit - block_bit);
 			}
 		}
+		if (serial_finish) {
+			// From the start of the round that overflowed (abs_bit, opos): every lane decodes the same
+			// tokens (uniform control flow, LDS broadcasts) from 1 KB stretches staged like a block
+			// header; lane 0 notes one item per OTZ_IX_G tokens until a token does not fit.
+			const u32 room = out_cap - opos;
+			u64 pos = abs_bit;
+			u32 got = 0, ntok = 0;
+			bool found = false;
+			while (!found && status == 0) {
+				const u32 hb = (u32) (pos >> 3);
+				{
+					const otz_u4 v = otz_k1_ld16 (in, n_in, (int64_t)hb + 16 * (int64_t)lane);
+					otz_wave_sync ();
+					u32 *d = &L.h.hdr_w[4u * lane];
+					d[0] = v.x;
+					d[1] = v.y;
+					d[2] = v.z;
+					d[3] = v.w;
+					otz_wave_sync ();
+				}
+				u32 rel = (u32) (pos & 7u);
+				while (rel + 128u <= 8u * 1024u) {
+					const otz_k1_tok tk = otz_k1_decode_bits (L, otz_k1_hbits (L, rel), otz_k1_hbits (L, rel + 32u));
+					if (tk.kind != 0 || got + tk.obytes > room) {
+						if (tk.kind == 2u || pos + tk.nbits > total_bits) {
+							status = OZG_ST_DATA; // (cannot happen on a chain the walks validated)
+						}
+						clip_abs = pos;
+						abs_bit = pos + tk.nbits;
+						found = true;
+						break;
+					}
+					if ((ntok & (OTZ_IX_G - 1u)) == 0) {
+						if (n_items + 2u > items_cap) {
+							status = OTZ_IX_OVERFLOW;
+							break;
+						}
+						if (lane == 0) {
+							otz_ix_item it;
+							it.bit = (u32) (pos - block_bit);
+							it.out = opos - block_out + got;
+							items[n_items] = it;
+						}
+						n_items++;
+					}
+					got += tk.obytes;
+					pos += tk.nbits;
+					rel += tk.nbits;
+					ntok++;
+				}
+			}
+			if (status == 0) {
+				opos += got;
+				end_bit = (u32) (clip_abs - block_bit);
+				status = OTZ_K1_ST_NEED_OUT;
+			}
+		}
 		if (status != 0 && status != OTZ_K1_ST_NEED_OUT) {
 			break;
 		}
@@ -1095,7 +1090,7 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 		head->clip_lo = (u32)clip_abs;
 		head->clip_hi = (u32) (clip_abs >> 32);
 	}
-	if (prof && lane == 0) {
+	if (PROF && prof && lane == 0) {
 		for (u32 i = 0; i < 10; i++) {
 			prof[i] = pc[i];
 		}

@@ -77,11 +77,10 @@ otz_plan_kernel(const ozg_entry *entries, u32 n, u64 src_len, u64 dst_len, u64 a
 }
 
 // One wavefront per entry, no workgroup barrier anywhere: the number of entries in flight
-// per CU is set by LDS (12 KB each) and registers alone.
-extern "C" __global__ void __launch_bounds__ (64)
-__attribute__ ((amdgpu_waves_per_eu (OTZ_K1_WPE, 8)))
-otz_index_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, u32 first, u32 n, u64 src_len, u64 dst_len, ozg_limits lim, u8 *arena, const otz_region *regions, otz_ix_head *heads,
-	u32 *ovf, u64 *prof) {
+// per CU is set by LDS (10 KB each) and registers alone.
+template <bool PROF>
+OTZ_DEV void otz_index_body(const u8 *src, u8 *dst, const ozg_entry *entries, u32 first, u32 n, u64 src_len, u64 dst_len, const ozg_limits &lim, u8 *arena,
+	const otz_region *regions, otz_ix_head *heads, u32 *ovf, u64 *prof) {
 	extern __shared__ __attribute__ ((aligned (16))) u8 otz_smem[];
 	const u32 i = first + blockIdx.x;
 	if (i >= n) {
@@ -93,9 +92,22 @@ otz_index_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, u32 first, u3
 		return;
 	}
 	const otz_region r = regions[i];
-	if (otz_run_index (L, src, dst, e, lim, &heads[i], arena + r.off, r.bytes, prof ? prof + 32ull * i + 16u : nullptr) && otz_lane () == 0) {
+	if (otz_run_index<PROF> (L, src, dst, e, lim, &heads[i], arena + r.off, r.bytes, PROF && prof ? prof + 32ull * i + 16u : nullptr) && otz_lane () == 0) {
 		ovf[1u + atomicAdd (&ovf[0], 1u)] = i; // ovf[0]: count, then the entries
 	}
+}
+
+extern "C" __global__ void __launch_bounds__ (64) __attribute__ ((amdgpu_waves_per_eu (OTZ_K1_WPE, 8)))
+otz_index_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, u32 first, u32 n, u64 src_len, u64 dst_len, ozg_limits lim, u8 *arena, const otz_region *regions, otz_ix_head *heads,
+	u32 *ovf, u64 *prof) {
+	otz_index_body<false> (src, dst, entries, first, n, src_len, dst_len, lim, arena, regions, heads, ovf, prof);
+}
+
+// the same with per-phase cycle counters (diagnostics: tools/prof_phases.py)
+extern "C" __global__ void __launch_bounds__ (64)
+otz_index_prof_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, u32 first, u32 n, u64 src_len, u64 dst_len, ozg_limits lim, u8 *arena, const otz_region *regions, otz_ix_head *heads,
+	u32 *ovf, u64 *prof) {
+	otz_index_body<true> (src, dst, entries, first, n, src_len, dst_len, lim, arena, regions, heads, ovf, prof);
 }
 
 extern "C" __global__ void __launch_bounds__ (OTZ_NT) __attribute__ ((amdgpu_waves_per_eu (4, 4)))
@@ -243,7 +255,7 @@ constexpr int MAX_DEV = 16;
 constexpr int N_SLOTS = 3; // asynchronous staged batches in flight per device
 
 std::mutex g_mu; // contexts, their buffers and slots
-u32 g_chunks = 1; // chunks of a large DEFLATE batch on two internal streams (OTEZIP_GPU_CHUNKS): measured slower than one launch pair (4.1 -> 4.4 ms at 4), kept for experiments
+u32 g_chunks = 1; // chunks of a large DEFLATE batch on two internal streams (OTEZIP_GPU_CHUNKS; 0 = cut at a whole number of index-kernel generations): neither measured faster than one launch pair (4.13 ms; 4 chunks 4.43, generation cut 4.14), kept for experiments
 ozg_limits g_limits = { 1000ull, 1024ull * 1024ull };
 u64 *g_prof = nullptr; // diagnostics: per-entry phase cycle counters (ozg_debug_set_profile_buffer)
 thread_local char g_err[256] = "";
@@ -287,6 +299,7 @@ namespace {
 
 struct dev_ctx {
 	bool ready = false;
+	u32 gen = 4096; // index wavefronts resident on the chip at once
 	staging stage; // synchronous host entry points
 	workspace ws;
 	ozg_job slots[N_SLOTS];
@@ -439,9 +452,17 @@ int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, 
 		hipLaunchKernelGGL (otz_plan_kernel, dim3 ((n + 255u) / 256u), dim3 (256), 0, s, d_entries, n, (u64)src_len, (u64)dst_len,
 			(u64)ws.arena_cap, ws.cursor, ws.regions, ws.heads);
 		OZG_HIP (hipGetLastError ());
-		const u32 n_chunks = n >= 4096u ? g_chunks : 1u;
+		// OTEZIP_GPU_CHUNKS=0: cut the batch where a whole number of index-kernel "generations" ends
+		// (one wavefront per entry, g_gen of them resident on the chip): the remainder's index
+		// kernel, which cannot fill the chip, then runs beside the first part's apply kernel
+		u32 n_chunks = n >= 4096u ? g_chunks : 1u;
+		u32 cut = 0;
+		if (g_chunks == 0) {
+			cut = n / C.gen * C.gen;
+			n_chunks = cut > 0 && cut < n && n - cut >= 256u ? 2u : 1u;
+		}
 		if (n_chunks <= 1u) {
-			hipLaunchKernelGGL (otz_index_kernel, dim3 (n), dim3 (64), sizeof (otz_k1_lds), s, (const u8 *)d_src, (u8 *)d_dst, d_entries, 0u, n,
+			hipLaunchKernelGGL (g_prof ? otz_index_prof_kernel : otz_index_kernel, dim3 (n), dim3 (64), sizeof (otz_k1_lds), s, (const u8 *)d_src, (u8 *)d_dst, d_entries, 0u, n,
 				(u64)src_len, (u64)dst_len, g_limits, ws.arena, ws.regions, ws.heads, ws.ovf, g_prof);
 			OZG_HIP (hipGetLastError ());
 			hipLaunchKernelGGL (otz_apply_kernel, dim3 (n), dim3 (OTZ_NT), sizeof (otz_inflate_lds), s, (const u8 *)d_src, (u8 *)d_dst,
@@ -453,7 +474,11 @@ int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, 
 				OZG_HIP (hipStreamWaitEvent (ws.aux[k], ws.fork, 0));
 			}
 			for (u32 c = 0; c < n_chunks; c++) {
-				const u32 e0 = (u32) ((u64)n * c / n_chunks), e1 = (u32) ((u64)n * (c + 1u) / n_chunks);
+				u32 e0 = (u32) ((u64)n * c / n_chunks), e1 = (u32) ((u64)n * (c + 1u) / n_chunks);
+				if (cut) {
+					e0 = c ? cut : 0u;
+					e1 = c ? n : cut;
+				}
 				hipStream_t cs = ws.aux[c & 1u];
 				hipLaunchKernelGGL (otz_index_kernel, dim3 (e1 - e0), dim3 (64), sizeof (otz_k1_lds), cs, (const u8 *)d_src, (u8 *)d_dst, d_entries, e0, n,
 					(u64)src_len, (u64)dst_len, g_limits, ws.arena, ws.regions, ws.heads, ws.ovf, g_prof);
@@ -533,6 +558,8 @@ int ozg_init(int device) {
 			(int)sizeof (otz_inflate_lds)));
 		OZG_HIP (hipFuncSetAttribute ((const void *)otz_index_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
 			(int)sizeof (otz_k1_lds)));
+		OZG_HIP (hipFuncSetAttribute ((const void *)otz_index_prof_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+			(int)sizeof (otz_k1_lds)));
 		OZG_HIP (hipFuncSetAttribute ((const void *)otz_copy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
 			(int)sizeof (otz_copy_lds)));
 		OZG_HIP (hipFuncSetAttribute ((const void *)otz_crc32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -541,11 +568,15 @@ int ozg_init(int device) {
 			(int)sizeof (otz_copy_lds)));
 		OZG_HIP (hipFuncSetAttribute ((const void *)otz_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
 			(int)sizeof (otz_enc_lds)));
+		int cus = 256, per_cu = 16;
+		(void)hipDeviceGetAttribute (&cus, hipDeviceAttributeMultiprocessorCount, device);
+		(void)hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu, otz_index_kernel, 64, sizeof (otz_k1_lds));
+		g_dev[device].gen = (u32) (cus > 0 ? cus : 256) * (u32) (per_cu > 0 ? per_cu : 16);
 		g_dev[device].ready = true;
 	}
 	if (const char *c = getenv ("OTEZIP_GPU_CHUNKS")) {
 		const int v = atoi (c);
-		g_chunks = v < 1 ? 1u : v > 64 ? 64u : (u32)v;
+		g_chunks = v < 0 ? 1u : v > 64 ? 64u : (u32)v;
 	}
 	g_cur = device;
 	if (g_default < 0) {

@@ -57,7 +57,7 @@ void *thread_main(void *p) {
 	if (a->phase == 3) {
 		otz_encode_entry (*(otz_enc_lds *)a->lds, a->src, a->dst, *a->enc_e, a->enc_r);
 	} else if (a->phase == 1) {
-		otz_run_index (*(otz_k1_lds *)a->lds, a->src, a->dst, *a->e, a->lim, a->head, a->region, a->region_bytes);
+		otz_run_index<false> (*(otz_k1_lds *)a->lds, a->src, a->dst, *a->e, a->lim, a->head, a->region, a->region_bytes);
 	} else if (a->phase == 2) {
 		otz_run_apply (*(otz_inflate_lds *)a->lds, a->src, a->dst, *a->e, a->r, a->lim, a->head, a->region, nullptr, a->end_bit);
 	} else if (a->e->method == OZG_METHOD_DEFLATE) {
