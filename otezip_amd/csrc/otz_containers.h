@@ -40,8 +40,9 @@ OTZ_DEV u32 otz_rd_le32(const u8 *p) { return (u32)p[0] | ((u32)p[1] << 8) | ((u
 OTZ_DEV u64 otz_rd_le64(const u8 *p) { return (u64)otz_rd_le32 (p) | ((u64)otz_rd_le32 (p + 4) << 32); }
 
 // R(M): CRC register reached from zero over src[0..n), optionally copying to dst.
-// dst must be 16-byte aligned when do_copy.  All work-items call; all get R.
-OTZ_DEV u32 otz_stream_crc(otz_copy_lds &L, const u8 *src, u8 *dst, u32 n, bool do_copy) {
+// dst_aligned: dst is 16-byte aligned (full-width aligned stores); otherwise the copy uses
+// unaligned 16-byte stores.  All work-items call; all get R.
+OTZ_DEV u32 otz_stream_crc(otz_copy_lds &L, const u8 *src, u8 *dst, u32 n, bool do_copy, bool dst_aligned = true) {
 	const u32 tid = otz_tid ();
 	const u32 nch = n >> 4, tail = n & 15u;
 	// front-pad with zero pieces so that the last real piece belongs to lane 255
@@ -67,7 +68,11 @@ OTZ_DEV u32 otz_stream_crc(otz_copy_lds &L, const u8 *src, u8 *dst, u32 n, bool 
 			if (ok[j]) {
 				u32 vi = tid + OTZ_CNT * (k + j);
 				if (do_copy) {
-					otz_st16_aligned (dst + 16ull * (vi - pad), v[j]);
+					if (dst_aligned) {
+						otz_st16_aligned (dst + 16ull * (vi - pad), v[j]);
+					} else {
+						otz_st16 (dst + 16ull * (vi - pad), v[j]);
+					}
 				}
 				r ^= otz_crc_chunk16 (0, v[j], L.t4);
 			}
@@ -79,7 +84,11 @@ OTZ_DEV u32 otz_stream_crc(otz_copy_lds &L, const u8 *src, u8 *dst, u32 n, bool 
 		if (vi >= pad) {
 			otz_u4 v = otz_ld16 (src + 16ull * (vi - pad));
 			if (do_copy) {
-				otz_st16_aligned (dst + 16ull * (vi - pad), v);
+				if (dst_aligned) {
+					otz_st16_aligned (dst + 16ull * (vi - pad), v);
+				} else {
+					otz_st16 (dst + 16ull * (vi - pad), v);
+				}
 			}
 			r ^= otz_crc_chunk16 (0, v, L.t4);
 		}
@@ -188,10 +197,12 @@ OTZ_DEV void otz_copy_entry(otz_copy_lds &L, const u8 *in, u32 n_in, u8 *out, u3
 	}
 
 	if (method == OZG_METHOD_ZSTD) {
-		// ref zstd.inc.c:488-705.  Blocks are copied where they land (their output
-		// offsets are not 16-byte aligned), the CRC is then taken over the output.
+		// ref zstd.inc.c:488-705.  Every block is read ONCE: copied to where it lands (its output
+		// offset is rarely 16-byte aligned: unaligned 16-byte stores) while its CRC register is
+		// taken from the same loads; the blocks' registers are stitched with x^(8 * length).
 		status = OZG_ST_OK;
 		u32 ip = 0, op = 0;
+		u32 reg = 0xFFFFFFFFu; // running CRC register of out[0, op)
 		if (n_in < 5) {
 			status = OZG_ST_BUF; // :490-492
 		} else if (otz_rd_le32 (in) != 0xFD2FB528u) {
@@ -227,7 +238,10 @@ OTZ_DEV void otz_copy_entry(otz_copy_lds &L, const u8 *in, u32 n_in, u8 *out, u3
 					status = OZG_ST_NEED_OUT - 1000; // partial hand-out, Z_OK with avail_out == 0 (:513-548)
 					break;
 				}
-				otz_copy_bytes (in + ip + 3u, out + op, bs);
+				if (bs) {
+					const u32 Rb = otz_stream_crc (L, in + ip + 3u, out + op, bs, true, (op & 15u) == 0);
+					reg = otz_gf_mul (reg, otz_xpow_bytes (bs)) ^ Rb;
+				}
 				op += bs;
 				ip += 3u + bs;
 				ended = (h & 1u) != 0;
@@ -246,13 +260,7 @@ OTZ_DEV void otz_copy_entry(otz_copy_lds &L, const u8 *in, u32 n_in, u8 *out, u3
 			otz_copy_result (res, status, total, 0, 0);
 			return;
 		}
-		// make the block copies visible to the whole workgroup, then CRC the output
-		otz_fence_release ();
-		otz_sync ();
-		otz_fence_acquire ();
-		u32 R = otz_stream_crc (L, out, out, op, false);
-		u32 crc = ~(otz_gf_mul (0xFFFFFFFFu, otz_xpow_bytes (op)) ^ R);
-		otz_copy_result (res, OZG_ST_OK, total, crc, expect_crc);
+		otz_copy_result (res, OZG_ST_OK, total, ~reg, expect_crc);
 		return;
 	}
 

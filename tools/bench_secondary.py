@@ -110,7 +110,7 @@ def main():
     report["deflate_decode_host_buffers_pcie_inclusive"] = dict(
         ms=dt * 1e3, out_GiBps=sum(e["uncomp_size"] for e in ents_d) / dt / 2**30, entries=len(tab),
         note="unpinned host buffers, synchronous H2D + kernel + D2H, includes ctypes marshalling")
-    print(json.dumps(report, indent=1))
+    print(json.dumps(report))
     oz.shutdown()
 
 
