@@ -1,15 +1,19 @@
 // otz_inflate.h -- raw DEFLATE (RFC 1951) decode of ONE archive entry by ONE
-// 256-lane workgroup.  Replaces inflateInit2(-15)/inflate(Z_FINISH)/inflateEnd
-// as otezip_extract_entry drives them (ref src/lib/otezip.c:490-532,
-// src/lib/deflate-dec.inc.c:452-518, :547-831) plus the CRC-32 of :668.
+// 512-lane workgroup, self-contained (no index).  Replaces
+// inflateInit2(-15)/inflate(Z_FINISH)/inflateEnd as otezip_extract_entry drives
+// them (ref src/lib/otezip.c:490-532, src/lib/deflate-dec.inc.c:452-518,
+// :547-831) plus the CRC-32 of :668.
 //
-// The reference walks the stream one bit at a time and searches every symbol
-// per bit.  A wavefront cannot win that way, so the work is reorganised:
+// Since round 2 this is the FALLBACK: entries normally go through the index
+// kernel (otz_huff_index.h) and the apply kernel (otz_lz_apply.h); only entries
+// whose index does not fit their arena region (OTZ_IX_OVERFLOW) are decoded here,
+// by otz_inflate_kernel over the overflow list.  The ring, bitmaps, table
+// builders, flush and CRC in this file are shared with the apply kernel.
 //
-//   * the entry's whole output lives in a 64 KiB LDS ring (the 32 KiB LZ77
-//     window never touches HBM); it is flushed with coalesced 16-byte stores
-//     and the CRC is taken from LDS on the way out;
-//   * Huffman decode is parallel INSIDE the stream: each round stages 4 KiB of
+//   * the entry's output passes through a 56 KiB LDS ring (32 KiB LZ77 window +
+//     one round of output; the window never touches HBM); it is flushed with
+//     coalesced 16-byte stores and the CRC is taken from LDS on the way out;
+//   * Huffman decode is parallel INSIDE the stream: each round stages 8 KiB of
 //     compressed bytes into LDS (coalesced 16-byte loads), every lane decodes
 //     the 128-bit subsequence that starts at its own speculative bit offset
 //     (pass A), then re-decodes from where its left neighbour really ended
