@@ -185,27 +185,38 @@ otz_crc32_kernel(const u8 *buf, const u64 *off, const u32 *len, u32 *crc, u32 n)
 	}
 }
 
-// DEFLATE encode / STORE of n independent buffers: one wavefront each (26 KB LDS)
+// DEFLATE encode / STORE of n independent buffers: one wavefront per buffer (26 KB LDS).  The grid is
+// persistent -- as many wavefronts as fit the chip, each taking the next buffer off a counter -- so
+// that the token scratch (OTZ_ENC_TOK_WORDS words per wavefront) is sized by the chip, not the batch.
 extern "C" __global__ void __launch_bounds__ (64)
-otz_encode_kernel(const u8 *src, u8 *dst, const ozg_enc_entry *entries, ozg_enc_result *results, u32 n, u64 src_len, u64 dst_len) {
+otz_encode_kernel(const u8 *src, u8 *dst, const ozg_enc_entry *entries, ozg_enc_result *results, u32 n, u64 src_len, u64 dst_len,
+	u32 *tok, u32 *cursor) {
 	extern __shared__ __attribute__ ((aligned (16))) u8 otz_smem[];
-	u32 i = blockIdx.x;
-	if (i >= n) {
-		return;
-	}
 	otz_enc_lds &L = *reinterpret_cast<otz_enc_lds *> (otz_smem);
-	ozg_enc_entry e = entries[i];
-	if (!otz_enc_entry_in_bounds (e, src_len, dst_len)) {
+	u32 *my_tok = tok + (size_t)blockIdx.x * OTZ_ENC_TOK_WORDS;
+	for (;;) {
+		u32 i = 0;
 		if (otz_tid () == 0) {
-			results[i].status = OZG_ST_INTERNAL;
-			results[i].comp_size = 0;
-			results[i].crc32 = 0;
-			results[i].method = e.method;
-			results[i].flags = 0;
+			i = atomicAdd (cursor, 1u);
 		}
-		return;
+		i = otz_uniform (i);
+		if (i >= n) {
+			break;
+		}
+		ozg_enc_entry e = entries[i];
+		if (!otz_enc_entry_in_bounds (e, src_len, dst_len)) {
+			if (otz_tid () == 0) {
+				results[i].status = OZG_ST_INTERNAL;
+				results[i].comp_size = 0;
+				results[i].crc32 = 0;
+				results[i].method = e.method;
+				results[i].flags = 0;
+			}
+			continue;
+		}
+		otz_encode_entry (L, src, dst, e, &results[i], my_tok);
+		otz_wave_sync ();
 	}
-	otz_encode_entry (L, src, dst, e, &results[i]);
 }
 
 // CRC-32 of every input buffer of an encode batch (ref src/lib/otezip.c:1124)
@@ -253,6 +264,7 @@ namespace {
 
 constexpr int MAX_DEV = 16;
 constexpr int N_SLOTS = 3; // asynchronous staged batches in flight per device
+constexpr u32 ENC_GRID = 256u * 6u; // encode wavefronts resident on the chip (26 KB of LDS each)
 
 std::mutex g_mu; // contexts, their buffers and slots
 u32 g_chunks = 1; // chunks of a large DEFLATE batch on two internal streams (OTEZIP_GPU_CHUNKS; 0 = cut at a whole number of index-kernel generations): neither measured faster than one launch pair (4.13 ms; 4 chunks 4.43, generation cut 4.14), kept for experiments
@@ -280,6 +292,12 @@ struct workspace {
 	bool busy = false;
 	hipStream_t aux[2] = { nullptr, nullptr };
 	hipEvent_t fork = nullptr, join[2] = { nullptr, nullptr };
+	// encode side: token scratch of the persistent grid, its buffer counter
+	u32 *enc_tok = nullptr;
+	u32 enc_grid = 0;
+	u32 *enc_cursor = nullptr;
+	hipEvent_t enc_done = nullptr;
+	bool enc_busy = false;
 };
 
 } // namespace
@@ -422,6 +440,11 @@ void ws_free(workspace &ws) {
 	(void)hipFree (ws.heads);
 	(void)hipFree (ws.cursor);
 	(void)hipFree (ws.ovf);
+	(void)hipFree (ws.enc_tok);
+	(void)hipFree (ws.enc_cursor);
+	if (ws.enc_done) {
+		(void)hipEventDestroy (ws.enc_done);
+	}
 	if (ws.done) {
 		(void)hipEventDestroy (ws.done);
 	}
@@ -833,9 +856,31 @@ int ozg_encode_batch_device(const void *d_src, uint64_t src_len, void *d_dst, ui
 		return OZG_E_ARG;
 	}
 	hipStream_t s = (hipStream_t)stream;
-	hipLaunchKernelGGL (otz_encode_kernel, dim3 (n), dim3 (64), sizeof (otz_enc_lds), s, (const u8 *)d_src, (u8 *)d_dst,
-		d_entries, d_results, n, (u64)src_len, (u64)dst_len);
+	workspace &ws = C->ws;
+	const u32 grid = n < ENC_GRID ? n : ENC_GRID;
+	if (!ws.enc_done) {
+		OZG_HIP (hipEventCreateWithFlags (&ws.enc_done, hipEventDisableTiming));
+		OZG_HIP (hipMalloc ((void **)&ws.enc_cursor, 256));
+	}
+	if (grid > ws.enc_grid) {
+		OZG_HIP (hipDeviceSynchronize ()); // an earlier batch may still use the scratch that is about to be freed
+		ws.enc_busy = false;
+		(void)hipFree (ws.enc_tok);
+		ws.enc_tok = nullptr;
+		ws.enc_grid = 0;
+		const u32 g = grid < 64u ? 64u : (grid + (grid >> 1) < ENC_GRID ? grid + (grid >> 1) : ENC_GRID);
+		OZG_HIP (hipMalloc ((void **)&ws.enc_tok, (size_t)g * OTZ_ENC_TOK_WORDS * sizeof (u32)));
+		ws.enc_grid = g;
+	}
+	if (ws.enc_busy) {
+		OZG_HIP (hipStreamWaitEvent (s, ws.enc_done, 0)); // the scratch is shared between streams
+	}
+	OZG_HIP (hipMemsetAsync (ws.enc_cursor, 0, 4, s));
+	hipLaunchKernelGGL (otz_encode_kernel, dim3 (grid), dim3 (64), sizeof (otz_enc_lds), s, (const u8 *)d_src, (u8 *)d_dst,
+		d_entries, d_results, n, (u64)src_len, (u64)dst_len, ws.enc_tok, ws.enc_cursor);
 	OZG_HIP (hipGetLastError ());
+	OZG_HIP (hipEventRecord (ws.enc_done, s));
+	ws.enc_busy = true;
 	hipLaunchKernelGGL (otz_enc_crc_kernel, dim3 (n), dim3 (256), sizeof (otz_copy_lds), s, (const u8 *)d_src, (u8 *)d_dst,
 		d_entries, d_results, n, (u64)src_len, (u64)dst_len);
 	OZG_HIP (hipGetLastError ());

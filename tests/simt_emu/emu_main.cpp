@@ -48,6 +48,7 @@ struct block_args {
 	u64 *end_bit;
 	const ozg_enc_entry *enc_e; // phase 3: encode kernel body
 	ozg_enc_result *enc_r;
+	u32 *enc_tok;
 };
 
 void *thread_main(void *p) {
@@ -55,7 +56,7 @@ void *thread_main(void *p) {
 	otz_emu_self.tid = a->tid;
 	otz_emu_self.blk = a->blk;
 	if (a->phase == 3) {
-		otz_encode_entry (*(otz_enc_lds *)a->lds, a->src, a->dst, *a->enc_e, a->enc_r);
+		otz_encode_entry (*(otz_enc_lds *)a->lds, a->src, a->dst, *a->enc_e, a->enc_r, a->enc_tok);
 	} else if (a->phase == 1) {
 		otz_run_index<false> (*(otz_k1_lds *)a->lds, a->src, a->dst, *a->e, a->lim, a->head, a->region, a->region_bytes);
 	} else if (a->phase == 2) {
@@ -260,15 +261,18 @@ extern "C" uint32_t emu_lds_bytes_copy(void) { return (uint32_t)sizeof (otz_copy
 
 // ---- encode side: one 64-thread workgroup per buffer (CRC is left to the caller in emulation)
 extern "C" int emu_encode_batch(const void *src, void *dst, const ozg_enc_entry *entries, ozg_enc_result *results, uint32_t n) {
+	u32 *tok = (u32 *)malloc (sizeof (u32) * OTZ_ENC_TOK_WORDS);
 	for (uint32_t i = 0; i < n; i++) {
 		results[i].status = -999;
 		block_args a = {};
 		a.src = (const u8 *)src;
 		a.dst = (u8 *)dst;
 		a.phase = 3;
+		a.enc_tok = tok;
 		a.enc_e = &entries[i];
 		a.enc_r = &results[i];
 		run_block (OTZ_ENC_NT, a, sizeof (otz_enc_lds));
 	}
+	free (tok);
 	return 0;
 }
