@@ -35,44 +35,55 @@
 //          7-bit-limited code.  The block is written with the fixed code instead when
 //          that is smaller (short inputs).
 //   EMIT   64 tokens per step: table lookups give every token its bits (at most 48), a wave
-//          prefix sum gives its bit offset, the tokens are OR-ed into a 2 KiB LDS bit
+//          prefix sum gives its bit offset, the tokens are OR-ed into a 1 KiB LDS bit
 //          buffer that is drained with coalesced 16-byte stores.
 //
-// LDS: 8 KiB input ring (matches reach 7 168 bytes back), 2048 two-way buckets, the bit
-// buffer, histograms, code tables and the scratch of the code construction: 26 KB per
-// wavefront, six buffers in flight per CU.
+// LDS: 8 KiB input ring (matches reach 7 278 bytes back), 2048 two-way buckets (the code
+// construction borrows their place between the parse and the emit of a block), the bit
+// buffer, histograms and code tables: 19.5 KB per wavefront, eight buffers in flight per CU.
 #pragma once
 
 #include "otz_simt.h"
 #include "../../include/otezip_gpu.h"
 
 #define OTZ_ENC_NT 64u
+#ifndef OTZ_ENC_WIN
 #define OTZ_ENC_WIN 8192u
+#endif
 #define OTZ_ENC_WMASK (OTZ_ENC_WIN - 1u)
 #define OTZ_ENC_LOAD 512u                 // bytes per refill of the ring
-#define OTZ_ENC_AHEAD (64u + 258u + 8u)   // a step looks this far beyond its first position
-#define OTZ_ENC_MAXDIST 7168u             // ring - AHEAD - LOAD - slack
+#ifndef OTZ_ENC_U
+#define OTZ_ENC_U 4u                      // steps of 64 positions in flight together (instruction-level parallelism)
+#endif
+#define OTZ_ENC_STEP (64u * OTZ_ENC_U)
+#define OTZ_ENC_AHEAD (OTZ_ENC_STEP + 258u + 8u) // an iteration looks this far beyond its first position
+#define OTZ_ENC_MAXDIST (OTZ_ENC_WIN - OTZ_ENC_AHEAD - OTZ_ENC_LOAD - 8u)
+#ifndef OTZ_ENC_WAYS
+#define OTZ_ENC_WAYS 1u                   // candidates per bucket: 1 (4096 buckets) or 2 (2048 buckets; +1.3 % ratio, +25 % work)
+#endif
 #ifndef OTZ_ENC_HBITS
-#define OTZ_ENC_HBITS 11u
+#define OTZ_ENC_HBITS (OTZ_ENC_WAYS == 2u ? 11u : 12u)
 #endif
 #define OTZ_ENC_HASH (1u << OTZ_ENC_HBITS)
-#define OTZ_ENC_OUT 2048u                 // bit buffer: drained by halves, a step adds at most 64 * 48 bits
+#define OTZ_ENC_HEAD_WORDS (OTZ_ENC_HASH * OTZ_ENC_WAYS / 2u)
+#ifndef OTZ_ENC_WALK
+#define OTZ_ENC_WALK 0                    // 1: pick the token chain by a scalar walk instead of pointer doubling
+#endif
+#define OTZ_ENC_OUT 1024u                 // bit buffer: drained by halves, a step adds at most 64 * 48 bits
 #define OTZ_ENC_BLOCK 65536u              // input bytes per DEFLATE block
 #define OTZ_ENC_MINLEN 4u
 #define OTZ_ENC_LAZY_MAX 32u              // a match at least this long is taken without looking at the next position
-#define OTZ_ENC_TOK_WORDS OTZ_ENC_BLOCK   // token scratch per wavefront: one u32 per input byte of a block (all literals)
+#define OTZ_ENC_TOK_WORDS (OTZ_ENC_BLOCK + 2048u) // scratch per wavefront: one u32 per input byte of a block (all literals)
+                                          // + where the part of the bucket table the code construction borrows is parked
 #define OTZ_ENC_DSYM 288u                 // distance symbols live at [288, 320) of hist / code / lens
 
-#define OTZ_TOK_MATCH 0x80000000u         // token: literal = byte; match = this | (len - 3) << 16 | (dist - 1)
+#define OTZ_TOK_MATCH 0x80000000u         // token: literal = byte; match = this | (length symbol - 257) << 23 | its extra bits << 18
+                                          //        | distance symbol << 13 | its extra bits
 
-struct otz_enc_lds {
-	u32 win_w[OTZ_ENC_WIN / 4];
-	u32 head[OTZ_ENC_HASH];  // bucket: [15:0] most recent position with this hash (mod 64 Ki), [31:16] the one before
-	u32 out_w[OTZ_ENC_OUT / 4]; // bit buffer: tokens are OR-ed in at their bit offsets
-	u32 hist[320];           // literal/length symbols at 0..287, distance symbols at 288..319
-	u32 code[320];           // same layout: bit-reversed code | length << 16
-	u8 lens[320];
-	// code construction scratch
+// scratch of the code construction and the header of a block: it lives where the bucket table is,
+// between the parse and the emit of a block (a buffer of more than one block parks that part of the
+// table in global memory meanwhile)
+struct otz_enc_build {
 	u32 sw[288];             // leaf weights, ascending
 	u32 iw[288];             // internal-node weights, in creation order
 	u16 ssym[288];           // symbol of the leaf with rank r
@@ -80,12 +91,31 @@ struct otz_enc_lds {
 	u16 ipar[288];           // parent of internal node k
 	u32 blc[16];             // leaves per code length
 	u32 base[16];            // next canonical code per length
+	u8 lens[320];            // code lengths, laid out like hist / code
 	// the code-length code
 	u32 clhist[32];
 	u32 clcode[32];
 	u8 cllens[32];
 	u16 cltok[320];          // run-length tokens: symbol | extra << 5
 	u32 n_cltok;
+	u32 pad[3];
+};
+#define OTZ_ENC_BUILD_U4 ((u32) (sizeof (otz_enc_build) / 16u))
+
+struct otz_enc_lds {
+	u32 win_w[OTZ_ENC_WIN / 4 + 4]; // the ring; its first 16 bytes are repeated behind its end, so that no read wraps
+#ifdef OTZ_ENC_DEBUG_NOALIAS
+	struct {
+#else
+	union {
+#endif
+		u32 head[OTZ_ENC_HEAD_WORDS]; // two ways: a word per bucket, [15:0] the most recent position with this hash
+		                              // (mod 64 Ki), [31:16] the one before; one way: a u16 per bucket
+		otz_enc_build b;
+	};
+	u32 out_w[OTZ_ENC_OUT / 4]; // bit buffer: tokens are OR-ed in at their bit offsets
+	u32 hist[320];           // literal/length symbols at 0..287, distance symbols at 288..319
+	u32 code[320];           // same layout: bit-reversed code | length << 16
 };
 
 struct otz_enc_state {
@@ -109,7 +139,7 @@ OTZ_DEV void otz_enc_or_bits(otz_enc_lds &L, u32 off, u32 v, u32 nbits) {
 OTZ_DEV void otz_enc_drain(otz_enc_lds &L, otz_enc_state &S) {
 	const u32 HALF_W = OTZ_ENC_OUT / 8, HALF_B = OTZ_ENC_OUT / 2;
 	while (S.bitpos >= HALF_B * 8u) {
-		otz_wave_sync ();
+		otz_wave_sync_lds ();
 		if (S.out_pos + HALF_B > S.cap) {
 			S.overflow = true;
 		} else {
@@ -117,12 +147,12 @@ OTZ_DEV void otz_enc_drain(otz_enc_lds &L, otz_enc_state &S) {
 				otz_st16_aligned (S.dst + S.out_pos + 16u * c, *reinterpret_cast<const otz_u4 *> (&L.out_w[4u * c]));
 			}
 		}
-		otz_wave_sync ();
+		otz_wave_sync_lds ();
 		for (u32 i = otz_tid (); i < HALF_W; i += OTZ_ENC_NT) {
 			L.out_w[i] = L.out_w[i + HALF_W];
 			L.out_w[i + HALF_W] = 0;
 		}
-		otz_wave_sync ();
+		otz_wave_sync_lds ();
 		S.out_pos += HALF_B;
 		S.bitpos -= HALF_B * 8u;
 	}
@@ -130,16 +160,8 @@ OTZ_DEV void otz_enc_drain(otz_enc_lds &L, otz_enc_state &S) {
 
 // Every lane contributes nb (0..48) bits: a wave prefix sum places them behind S.bitpos, in lane order.
 OTZ_DEV void otz_enc_put(otz_enc_lds &L, otz_enc_state &S, u64 bits, u32 nb) {
-	const u32 lane = otz_tid ();
-	u32 incl = nb;
-#pragma unroll
-	for (u32 d = 1; d < 64; d <<= 1) {
-		u32 o = otz_shfl_up (incl, d);
-		if (lane >= d) {
-			incl += o;
-		}
-	}
-	const u32 total = otz_shfl (incl, 63);
+	const u32 incl = otz_wave_scan_incl (nb);
+	const u32 total = otz_readlane (incl, 63);
 	if (nb) {
 		const u32 off = S.bitpos + incl - nb, w = off >> 5, sh = off & 31u;
 		const u64 lo = bits << sh;
@@ -209,34 +231,22 @@ OTZ_DEV u32 otz_enc_dist_sym(u32 dist, u32 *xb, u32 *xv) {
 	return 2u * hb + ((d >> b) & 1u);
 }
 
-// eight bytes of the ring starting at byte position q: three dword-aligned reads
+// eight bytes of the ring starting at byte position q: the three dwords that hold them (one 8-byte
+// and one 4-byte read, both dword-aligned) and two v_alignbyte
 OTZ_DEV u64 otz_enc_ld8(const otz_enc_lds &L, u32 q) {
-	const u32 i = q >> 2, s = q & 3u, M = OTZ_ENC_WIN / 4u - 1u;
-	const u32 w0 = L.win_w[i & M], w1 = L.win_w[(i + 1u) & M], w2 = L.win_w[(i + 2u) & M];
-	return (u64)otz_alignbyte (w1, w0, s) | (u64)otz_alignbyte (w2, w1, s) << 32;
+	const u32 b = q & OTZ_ENC_WMASK, i = b >> 2, s = b & 3u;
+	const u64 w01 = otz_ld64u (&L.win_w[i]);
+	const u32 w2 = L.win_w[i + 2u];
+	return (u64)otz_alignbyte ((u32) (w01 >> 32), (u32)w01, s) | (u64)otz_alignbyte (w2, (u32) (w01 >> 32), s) << 32;
 }
 
-// length of the match between position pos and pos - dist (0 if shorter than the minimum), at most maxlen
-OTZ_DEV u32 otz_enc_measure(const otz_enc_lds &L, u32 pos, u32 dist, u64 own, u32 maxlen) {
-	u64 x = own ^ otz_enc_ld8 (L, pos - dist);
-	if ((u32)x != 0u) {
-		return 0; // fewer than four bytes
+// 16 bytes into the ring at position q (a multiple of 16)
+OTZ_DEV void otz_enc_ring_put16(otz_enc_lds &L, u32 q, otz_u4 v) {
+	const u32 b = q & OTZ_ENC_WMASK;
+	*reinterpret_cast<otz_u4 *> (&L.win_w[b >> 2]) = v;
+	if (b == 0u) {
+		*reinterpret_cast<otz_u4 *> (&L.win_w[OTZ_ENC_WIN / 4u]) = v;
 	}
-	u32 k = 8;
-	if (x != 0ull) {
-		k = otz_ctz64 (x) >> 3;
-	} else {
-		while (k < maxlen) {
-			x = otz_enc_ld8 (L, pos + k) ^ otz_enc_ld8 (L, pos - dist + k);
-			if (x != 0ull) {
-				k += otz_ctz64 (x) >> 3;
-				break;
-			}
-			k += 8u;
-		}
-	}
-	k = k < maxlen ? k : maxlen;
-	return k >= OTZ_ENC_MINLEN ? k : 0u;
 }
 
 OTZ_DEV u32 otz_enc_wave_sum(u32 v) {
@@ -263,7 +273,7 @@ OTZ_DEV void otz_enc_build_code(otz_enc_lds &L, u32 *freq, u32 nsym, u32 limit, 
 		m += otz_popc64 (otz_ballot (i < nsym && freq[i] != 0u));
 	}
 	if (m < 2u) {
-		otz_wave_sync ();
+		otz_wave_sync_lds ();
 		if (lane == 0) {
 			u32 mm = m;
 			for (u32 s = 0; s < 3u && mm < 2u; s++) {
@@ -274,7 +284,7 @@ OTZ_DEV void otz_enc_build_code(otz_enc_lds &L, u32 *freq, u32 nsym, u32 limit, 
 			}
 		}
 		m = 2;
-		otz_wave_sync ();
+		otz_wave_sync_lds ();
 	}
 	// rank by (weight, symbol)
 	u32 key[NCH], rk[NCH];
@@ -299,83 +309,83 @@ OTZ_DEV void otz_enc_build_code(otz_enc_lds &L, u32 *freq, u32 nsym, u32 limit, 
 #pragma unroll
 	for (u32 k = 0; k < NCH; k++) {
 		if (key[k]) {
-			L.sw[rk[k]] = key[k] >> 9;
-			L.ssym[rk[k]] = (u16) (key[k] & 511u);
+			L.b.sw[rk[k]] = key[k] >> 9;
+			L.b.ssym[rk[k]] = (u16) (key[k] & 511u);
 		}
 	}
 	if (lane < 16u) {
-		L.blc[lane] = 0;
+		L.b.blc[lane] = 0;
 	}
-	otz_wave_sync ();
+	otz_wave_sync_lds ();
 	// two-queue merge: leaves in ascending order, internal nodes in creation order (also ascending)
 	if (lane == 0) {
 		u32 li = 0, ih = 0;
-		u32 lw = L.sw[0], inw = 0xFFFFFFFFu;
+		u32 lw = L.b.sw[0], inw = 0xFFFFFFFFu;
 		for (u32 k = 0; k + 1u < m; k++) {
 			u32 sum = 0;
 			for (u32 t = 0; t < 2u; t++) {
 				if (li < m && lw <= inw) {
 					sum += lw;
-					L.lpar[li] = (u16)k;
+					L.b.lpar[li] = (u16)k;
 					li++;
-					lw = li < m ? L.sw[li] : 0xFFFFFFFFu;
+					lw = li < m ? L.b.sw[li] : 0xFFFFFFFFu;
 				} else {
 					sum += inw;
-					L.ipar[ih] = (u16)k;
+					L.b.ipar[ih] = (u16)k;
 					ih++;
-					inw = ih < k ? L.iw[ih] : 0xFFFFFFFFu;
+					inw = ih < k ? L.b.iw[ih] : 0xFFFFFFFFu;
 				}
 			}
-			L.iw[k] = sum;
+			L.b.iw[k] = sum;
 			if (ih == k) {
 				inw = sum; // the queue of internal nodes was empty: the new node is its head
 			}
 		}
 	}
-	otz_wave_sync ();
+	otz_wave_sync_lds ();
 	// leaf depths, clamped; K = Kraft sum in units of 2^-limit
 	u32 K = 0;
 #pragma unroll
 	for (u32 k = 0; k < NCH; k++) {
 		const u32 r = lane + 64u * k;
 		if (r < m) {
-			u32 d = 1, q = L.lpar[r];
+			u32 d = 1, q = L.b.lpar[r];
 			while (q != m - 2u) {
-				q = L.ipar[q];
+				q = L.b.ipar[q];
 				d++;
 			}
 			d = d < limit ? d : limit;
-			otz_lds_add (&L.blc[d], 1u);
+			otz_lds_add (&L.b.blc[d], 1u);
 			K += 1u << (limit - d);
 		}
 	}
 	K = otz_enc_wave_sum (K);
-	otz_wave_sync ();
+	otz_wave_sync_lds ();
 	if (K > (1u << limit) && lane == 0) {
 		// too deep a tree was cut off at `limit`: every round turns a leaf above the limit into
 		// a node with two leaves below it, one of them taken from the bottom row: Kraft sum - 1
 		for (u32 over = K - (1u << limit); over > 0; over--) {
 			u32 b = limit - 1u;
-			while (L.blc[b] == 0u) {
+			while (L.b.blc[b] == 0u) {
 				b--;
 			}
-			L.blc[b]--;
-			L.blc[b + 1u] += 2u;
-			L.blc[limit]--;
+			L.b.blc[b]--;
+			L.b.blc[b + 1u] += 2u;
+			L.b.blc[limit]--;
 		}
 	}
-	otz_wave_sync ();
+	otz_wave_sync_lds ();
 	// deal the lengths out again in rank order (lightest leaf = longest code), first canonical codes
 	{
 		u32 c = 0, mine = 0;
 		for (u32 b = 1; b <= limit; b++) {
-			c = (c + L.blc[b - 1u]) << 1;
+			c = (c + L.b.blc[b - 1u]) << 1;
 			if (lane == b) {
 				mine = c;
 			}
 		}
 		if (lane >= 1u && lane < 16u) {
-			L.base[lane] = mine;
+			L.b.base[lane] = mine;
 		}
 	}
 #pragma unroll
@@ -384,16 +394,16 @@ OTZ_DEV void otz_enc_build_code(otz_enc_lds &L, u32 *freq, u32 nsym, u32 limit, 
 		if (r < m) {
 			u32 cum = 0, len = 0;
 			for (u32 b = limit; b >= 1u; b--) {
-				const u32 c = L.blc[b];
+				const u32 c = L.b.blc[b];
 				if (r >= cum && r < cum + c) {
 					len = b;
 				}
 				cum += c;
 			}
-			lens[L.ssym[r]] = (u8)len;
+			lens[L.b.ssym[r]] = (u8)len;
 		}
 	}
-	otz_wave_sync ();
+	otz_wave_sync_lds ();
 	// canonical codes: symbols of one length in symbol order
 #pragma unroll
 	for (u32 k = 0; k < NCH; k++) {
@@ -413,20 +423,20 @@ OTZ_DEV void otz_enc_build_code(otz_enc_lds &L, u32 *freq, u32 nsym, u32 limit, 
 		if (i < nsym) {
 			u32 e = 0;
 			if (len) {
-				const u32 c = L.base[len] + otz_popc64 (same & ((1ull << lane) - 1ull));
+				const u32 c = L.b.base[len] + otz_popc64 (same & ((1ull << lane) - 1ull));
 				e = (otz_brev (c) >> (32u - len)) | len << 16;
 			}
 			code[i] = e;
 		}
-		otz_wave_sync ();
+		otz_wave_sync_lds ();
 		if (lane >= 1u && lane < 16u) {
-			L.base[lane] += add;
+			L.b.base[lane] += add;
 		}
-		otz_wave_sync ();
+		otz_wave_sync_lds ();
 	}
 }
 
-// Run-length tokens (code-length alphabet, RFC 1951 3.2.7) for lens[0..n), appended to L.cltok; one lane.
+// Run-length tokens (code-length alphabet, RFC 1951 3.2.7) for lens[0..n), appended to L.b.cltok; one lane.
 OTZ_DEV u32 otz_enc_rle_lengths(otz_enc_lds &L, const u8 *lens, u32 n, u32 nt) {
 	u32 i = 0;
 	while (i < n) {
@@ -439,24 +449,24 @@ OTZ_DEV u32 otz_enc_rle_lengths(otz_enc_lds &L, const u8 *lens, u32 n, u32 nt) {
 		if (v == 0u) {
 			while (r >= 11u) {
 				const u32 t = r < 138u ? r : 138u;
-				L.cltok[nt++] = (u16) (18u | (t - 11u) << 5);
+				L.b.cltok[nt++] = (u16) (18u | (t - 11u) << 5);
 				r -= t;
 			}
 			if (r >= 3u) {
-				L.cltok[nt++] = (u16) (17u | (r - 3u) << 5);
+				L.b.cltok[nt++] = (u16) (17u | (r - 3u) << 5);
 				r = 0;
 			}
 		} else {
-			L.cltok[nt++] = (u16)v;
+			L.b.cltok[nt++] = (u16)v;
 			r--;
 			while (r >= 3u) {
 				const u32 t = r < 6u ? r : 6u;
-				L.cltok[nt++] = (u16) (16u | (t - 3u) << 5);
+				L.b.cltok[nt++] = (u16) (16u | (t - 3u) << 5);
 				r -= t;
 			}
 		}
 		while (r > 0u) {
-			L.cltok[nt++] = (u16)v;
+			L.b.cltok[nt++] = (u16)v;
 			r--;
 		}
 	}
@@ -466,8 +476,23 @@ OTZ_DEV u32 otz_enc_rle_lengths(otz_enc_lds &L, const u8 *lens, u32 n, u32 nt) {
 // Encode src[0..n) into dst (capacity cap); tok = OTZ_ENC_TOK_WORDS words of scratch.  All 64
 // work-items call together and all get the compressed size, or ~0u when the output does not
 // fit (the caller then stores the entry, ref otezip.c:846-850).
-OTZ_DEV u32 otz_deflate_entry(otz_enc_lds &L, const u8 *src, u32 n, u8 *dst, u32 cap, u32 *tok) {
+// prof (diagnostic builds): 16 x u64 cycle counters -- 0 ring refill + hash + bucket, 1 match measuring,
+// 2 chain selection, 3 tokens + histogram, 4 litlen code, 5 distance code, 6 run-length + its code + cost,
+// 7 header, 8 token emit, 15 total
+#define OTZ_ENC_MARK(i) \
+	do { \
+		if (PROF) { \
+			const u64 _t = otz_cycles (); \
+			pc[i] += _t - plast; \
+			plast = _t; \
+		} \
+	} while (0)
+template <bool PROF>
+OTZ_DEV u32 otz_deflate_entry(otz_enc_lds &L, const u8 *src, u32 n, u8 *dst, u32 cap, u32 *tok, u64 *prof = nullptr) {
 	const u32 lane = otz_tid ();
+	u64 pc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+	u64 plast = PROF ? otz_cycles () : 0;
+	const u64 pstart = plast;
 	const u64 lt_mask = (1ull << lane) - 1ull;
 	otz_enc_state S;
 	S.bitpos = 0;
@@ -475,14 +500,18 @@ OTZ_DEV u32 otz_deflate_entry(otz_enc_lds &L, const u8 *src, u32 n, u8 *dst, u32
 	S.cap = cap;
 	S.dst = dst;
 	S.overflow = false;
-	for (u32 i = lane; i < OTZ_ENC_HASH; i += OTZ_ENC_NT) {
+	for (u32 i = lane; i < OTZ_ENC_HEAD_WORDS; i += OTZ_ENC_NT) {
 		L.head[i] = 0;
 	}
 	for (u32 i = lane; i < OTZ_ENC_OUT / 4; i += OTZ_ENC_NT) {
 		L.out_w[i] = 0;
 	}
 	u32 loaded = 0, skip = 0;
-	otz_wave_sync ();
+	otz_u4 pre = { 0, 0, 0, 0 }; // the next refill of the ring, in flight
+	if (lane < OTZ_ENC_LOAD / 16u && 16u * lane + 16u <= n) {
+		pre = otz_ld16 (src + 16u * lane);
+	}
+	otz_wave_sync_lds ();
 	for (u32 bstart = 0; bstart < n && !S.overflow; bstart += OTZ_ENC_BLOCK) {
 		const u32 bend = n - bstart < OTZ_ENC_BLOCK ? n : bstart + OTZ_ENC_BLOCK;
 		for (u32 i = lane; i < 320u; i += OTZ_ENC_NT) {
@@ -491,132 +520,250 @@ OTZ_DEV u32 otz_deflate_entry(otz_enc_lds &L, const u8 *src, u32 n, u8 *dst, u32
 		u32 ntok = 0;
 		otz_wave_sync ();
 		// ------------------------------------------------------------------ PARSE
-		for (u32 p = bstart; p < bend; p += 64u) {
-			// keep [p - MAXDIST, p + AHEAD) resident in the ring
+		for (u32 p = bstart; p < bend; p += OTZ_ENC_STEP) {
+			// keep [p - MAXDIST, p + AHEAD) resident in the ring; the next refill is already on its way
 			while (loaded < n && p + OTZ_ENC_AHEAD > loaded) {
 				const u32 q = loaded + 16u * lane;
 				if (lane < OTZ_ENC_LOAD / 16u) {
 					if (q + 16u <= n) {
-						*reinterpret_cast<otz_u4 *> (&L.win_w[(q & OTZ_ENC_WMASK) >> 2]) = otz_ld16 (src + q);
+						otz_enc_ring_put16 (L, q, pre);
 					} else {
 						u8 *wb = reinterpret_cast<u8 *> (L.win_w);
 						for (u32 t = q; t < n; t++) {
 							wb[t & OTZ_ENC_WMASK] = src[t];
+							if ((t & OTZ_ENC_WMASK) < 16u) {
+								wb[OTZ_ENC_WIN + (t & OTZ_ENC_WMASK)] = src[t];
+							}
 						}
 					}
 				}
 				loaded += OTZ_ENC_LOAD;
-			}
-			otz_wave_sync ();
-			const u32 pos = p + lane;
-			const bool can = pos + OTZ_ENC_MINLEN <= n;
-			const u64 own = otz_enc_ld8 (L, pos);
-			const u32 h = ((u32)own * 0x9E3779B1u) >> (32u - OTZ_ENC_HBITS);
-			const u32 c = can ? L.head[h] : 0u;
-			otz_wave_sync (); // every lane has read the buckets of the earlier steps
-			if (can) {
-				L.head[h] = c << 16 | (pos & 0xFFFFu);
-			}
-			u32 len = 0, dist = 0;
-			if (can && lane >= skip) {
-				const u32 maxlen = n - pos < 258u ? n - pos : 258u;
-				const u32 d0 = (pos - c) & 0xFFFFu, d1 = (pos - (c >> 16)) & 0xFFFFu;
-				if (d0 >= 1u && d0 <= OTZ_ENC_MAXDIST && d0 <= pos) {
-					len = otz_enc_measure (L, pos, d0, own, maxlen);
-					dist = d0;
+				if (lane < OTZ_ENC_LOAD / 16u && q + OTZ_ENC_LOAD + 16u <= n) {
+					pre = otz_ld16 (src + q + OTZ_ENC_LOAD);
 				}
-				if (d1 >= 1u && d1 <= OTZ_ENC_MAXDIST && d1 <= pos && d1 != d0 && len < maxlen) {
-					const u32 l1 = otz_enc_measure (L, pos, d1, own, maxlen);
-					if (l1 > len) {
-						len = l1;
-						dist = d1;
+			}
+			otz_wave_sync_lds ();
+			u32 pos[OTZ_ENC_U], h[OTZ_ENC_U], c[OTZ_ENC_U], len[OTZ_ENC_U], dist[OTZ_ENC_U];
+			u64 own[OTZ_ENC_U];
+			bool can[OTZ_ENC_U];
+#pragma unroll
+			for (u32 u = 0; u < OTZ_ENC_U; u++) {
+				pos[u] = p + 64u * u + lane;
+				can[u] = pos[u] + OTZ_ENC_MINLEN <= n;
+				own[u] = otz_enc_ld8 (L, pos[u]);
+				h[u] = ((u32)own[u] * 0x9E3779B1u) >> (32u - OTZ_ENC_HBITS);
+			}
+#pragma unroll
+			for (u32 u = 0; u < OTZ_ENC_U; u++) {
+				c[u] = OTZ_ENC_WAYS == 2u ? L.head[h[u]] : (u32)reinterpret_cast<const u16 *> (L.head)[h[u]];
+			}
+			otz_wave_sync_lds (); // every lane has read the buckets of the earlier steps
+#pragma unroll
+			for (u32 u = 0; u < OTZ_ENC_U; u++) {
+				// (the last three positions of a buffer, and lanes beyond its end, hash bytes that are
+				// not theirs: nothing probes after them, and `can` keeps them from matching)
+				if (OTZ_ENC_WAYS == 2u) {
+					L.head[h[u]] = c[u] << 16 | (pos[u] & 0xFFFFu);
+				} else {
+					reinterpret_cast<u16 *> (L.head)[h[u]] = (u16)pos[u];
+				}
+			}
+			OTZ_ENC_MARK (0);
+			// all candidates of all steps are measured together: one LDS round trip per eight bytes
+			u32 cd[OTZ_ENC_U][OTZ_ENC_WAYS], cl[OTZ_ENC_U][OTZ_ENC_WAYS], maxlen[OTZ_ENC_U];
+			bool act[OTZ_ENC_U][OTZ_ENC_WAYS];
+			bool any = false;
+#pragma unroll
+			for (u32 u = 0; u < OTZ_ENC_U; u++) {
+				maxlen[u] = n - pos[u] < 258u ? n - pos[u] : 258u;
+				const bool open = can[u] && 64u * u + lane >= skip;
+				const u32 reach = pos[u] < OTZ_ENC_MAXDIST ? pos[u] : OTZ_ENC_MAXDIST; // the farthest a match may lie back
+#pragma unroll
+				for (u32 w = 0; w < OTZ_ENC_WAYS; w++) {
+					const u32 d = (pos[u] - (w ? c[u] >> 16 : c[u])) & 0xFFFFu;
+					cd[u][w] = d;
+					cl[u][w] = 0;
+					act[u][w] = false;
+					// (the candidate's bytes are read whether or not it is one: any address is inside the
+					// ring, and all the reads of an iteration are in flight together)
+					const bool valid = open && d - 1u < reach && (w == 0u || d != cd[u][0]);
+					const u64 x = own[u] ^ otz_enc_ld8 (L, pos[u] - d);
+					const u32 m8 = x != 0ull ? otz_ctz64 (x) >> 3 : 8u;
+					cl[u][w] = valid ? m8 : 0u;
+					act[u][w] = valid && m8 == 8u && 8u < maxlen[u];
+					any = any || act[u][w];
+				}
+			}
+			for (u32 k = 8; otz_ballot (any) != 0ull; k += 8u) {
+				// (branch-free, and every read of the round in flight together: the wavefront goes
+				// round as long as any lane has a live match, so a finished lane costs the same)
+				u64 o[OTZ_ENC_U], cb[OTZ_ENC_U][OTZ_ENC_WAYS];
+#pragma unroll
+				for (u32 u = 0; u < OTZ_ENC_U; u++) {
+					o[u] = otz_enc_ld8 (L, pos[u] + k);
+#pragma unroll
+					for (u32 w = 0; w < OTZ_ENC_WAYS; w++) {
+						cb[u][w] = otz_enc_ld8 (L, pos[u] - cd[u][w] + k);
+					}
+				}
+				any = false;
+#pragma unroll
+				for (u32 u = 0; u < OTZ_ENC_U; u++) {
+#pragma unroll
+					for (u32 w = 0; w < OTZ_ENC_WAYS; w++) {
+						const u64 x = o[u] ^ cb[u][w];
+						const u32 m8 = x != 0ull ? otz_ctz64 (x) >> 3 : 8u;
+						cl[u][w] += act[u][w] ? m8 : 0u;
+						act[u][w] = act[u][w] && m8 == 8u && k + 8u < maxlen[u];
+						any = any || act[u][w];
 					}
 				}
 			}
-			if (skip >= 64u) {
-				skip -= 64u; // the whole step lies inside the previous match
-				continue;
-			}
-			// lazy evaluation, then where the chain goes from every position
-			const u32 lnext = otz_shfl (len, (lane + 1u) & 63u);
-			const bool take = len != 0u && (len >= OTZ_ENC_LAZY_MAX || lane == 63u || lnext <= len);
-			u32 J = lane + (take ? len : 1u);
-			u64 R = 1ull << lane;
 #pragma unroll
-			for (u32 k = 0; k < 6u; k++) {
-				const u32 from = J & 63u;
-				const u32 Jn = otz_shfl (J, from);
-				const u32 Rlo = otz_shfl ((u32)R, from), Rhi = otz_shfl ((u32) (R >> 32), from);
-				if (J < 64u) {
-					R |= (u64)Rhi << 32 | Rlo;
-					J = Jn;
+			for (u32 u = 0; u < OTZ_ENC_U; u++) {
+				const u32 l0 = cl[u][0] < maxlen[u] ? cl[u][0] : maxlen[u];
+				const u32 l1 = OTZ_ENC_WAYS == 2u ? (cl[u][OTZ_ENC_WAYS - 1u] < maxlen[u] ? cl[u][OTZ_ENC_WAYS - 1u] : maxlen[u]) : 0u;
+				len[u] = l1 > l0 ? l1 : l0;
+				dist[u] = l1 > l0 ? cd[u][OTZ_ENC_WAYS - 1u] : cd[u][0];
+				len[u] = len[u] >= OTZ_ENC_MINLEN ? len[u] : 0u;
+			}
+			OTZ_ENC_MARK (1);
+			// lazy evaluation, then where the chain goes from every position (all steps at once)
+			u32 J[OTZ_ENC_U];
+			u64 R[OTZ_ENC_U];
+			bool take[OTZ_ENC_U];
+#pragma unroll
+			for (u32 u = 0; u < OTZ_ENC_U; u++) {
+				const u32 fill = u + 1u < OTZ_ENC_U ? otz_readlane (len[u + 1u < OTZ_ENC_U ? u + 1u : u], 0) : 0u;
+				const u32 lnext = otz_lane_down1 (len[u], fill);
+				take[u] = len[u] != 0u && (len[u] >= OTZ_ENC_LAZY_MAX || lnext <= len[u]);
+				J[u] = lane + (take[u] ? len[u] : 1u);
+				R[u] = 1ull << lane;
+			}
+#if !OTZ_ENC_WALK
+			// (the first round needs no mask from the other lane: one hop reaches J itself)
+#pragma unroll
+			for (u32 u = 0; u < OTZ_ENC_U; u++) {
+				const u32 Jn = otz_shfl (J[u], J[u] & 63u);
+				if (J[u] < 64u) {
+					R[u] |= 1ull << J[u];
+					J[u] = Jn;
 				}
 			}
-			const u32 lim = n - p < 64u ? n - p : 64u;
-			u64 sel = (u64)otz_readlane ((u32)R, skip) | (u64)otz_readlane ((u32) (R >> 32), skip) << 32;
-			if (lim < 64u) {
-				sel &= (1ull << lim) - 1ull;
-			}
-			skip = otz_readlane (J, skip) - 64u;
-			if ((sel >> lane) & 1ull) {
-				u32 t;
-				if (take) {
-					u32 xb, xv;
-					t = OTZ_TOK_MATCH | (len - 3u) << 16 | (dist - 1u);
-					otz_lds_add (&L.hist[otz_enc_len_sym (len, &xb, &xv)], 1u);
-					otz_lds_add (&L.hist[OTZ_ENC_DSYM + otz_enc_dist_sym (dist, &xb, &xv)], 1u);
-				} else {
-					t = (u32)own & 0xFFu;
-					otz_lds_add (&L.hist[t], 1u);
+#pragma unroll
+			for (u32 k = 1; k < 6u; k++) {
+#pragma unroll
+				for (u32 u = 0; u < OTZ_ENC_U; u++) {
+					const u32 from = J[u] & 63u;
+					const u32 Jn = otz_shfl (J[u], from);
+					const u32 Rlo = otz_shfl ((u32)R[u], from), Rhi = otz_shfl ((u32) (R[u] >> 32), from);
+					if (J[u] < 64u) {
+						R[u] |= (u64)Rhi << 32 | Rlo;
+						J[u] = Jn;
+					}
 				}
-				tok[ntok + otz_popc64 (sel & lt_mask)] = t;
 			}
-			ntok += otz_popc64 (sel);
+#endif
+			OTZ_ENC_MARK (2);
+#pragma unroll
+			for (u32 u = 0; u < OTZ_ENC_U; u++) {
+				if (skip >= 64u) {
+					skip -= 64u; // the whole step lies inside the previous match
+					continue;
+				}
+				if (p + 64u * u >= n) {
+					break;
+				}
+				const u32 left = n - (p + 64u * u), lim = left < 64u ? left : 64u;
+#if OTZ_ENC_WALK
+				u64 sel = 0;
+				u32 cur = skip;
+				while (cur < 64u) {
+					sel |= 1ull << cur;
+					cur = otz_readlane (J[u], cur);
+				}
+				skip = cur - 64u;
+#else
+				u64 sel = (u64)otz_readlane ((u32)R[u], skip) | (u64)otz_readlane ((u32) (R[u] >> 32), skip) << 32;
+				skip = otz_readlane (J[u], skip) - 64u;
+#endif
+				if (lim < 64u) {
+					sel &= (1ull << lim) - 1ull;
+				}
+				if ((sel >> lane) & 1ull) {
+					u32 t;
+					if (take[u]) {
+						u32 xb, lxv, dxv;
+						const u32 ls = otz_enc_len_sym (len[u], &xb, &lxv), ds = otz_enc_dist_sym (dist[u], &xb, &dxv);
+						t = OTZ_TOK_MATCH | (ls - 257u) << 23 | lxv << 18 | ds << 13 | dxv;
+						otz_lds_add (&L.hist[ls], 1u);
+						otz_lds_add (&L.hist[OTZ_ENC_DSYM + ds], 1u);
+					} else {
+						t = (u32)own[u] & 0xFFu;
+						otz_lds_add (&L.hist[t], 1u);
+					}
+					tok[ntok + otz_popc64 (sel & lt_mask)] = t;
+				}
+				ntok += otz_popc64 (sel);
+			}
+			OTZ_ENC_MARK (3);
 		}
 		otz_wave_sync ();
 		// ------------------------------------------------------------------ CODE
+		const bool more = bend < n;
+		if (more) {
+			for (u32 i = lane; i < OTZ_ENC_BUILD_U4; i += OTZ_ENC_NT) {
+				otz_st16_aligned (tok + OTZ_ENC_BLOCK + 4u * i, *reinterpret_cast<const otz_u4 *> (&L.head[4u * i]));
+			}
+			otz_wave_sync_lds ();
+		}
 		if (lane == 0) {
 			L.hist[256] = 1; // the end-of-block code
 		}
-		otz_wave_sync ();
-		otz_enc_build_code<5> (L, L.hist, 286u, 15u, L.lens, L.code);
-		otz_enc_build_code<1> (L, L.hist + OTZ_ENC_DSYM, 30u, 15u, L.lens + OTZ_ENC_DSYM, L.code + OTZ_ENC_DSYM);
-		otz_wave_sync ();
+		for (u32 i = lane; i < 320u; i += OTZ_ENC_NT) {
+			L.b.lens[i] = 0;
+		}
+		otz_wave_sync_lds ();
+		otz_enc_build_code<5> (L, L.hist, 286u, 15u, L.b.lens, L.code);
+		OTZ_ENC_MARK (4);
+		otz_enc_build_code<1> (L, L.hist + OTZ_ENC_DSYM, 30u, 15u, L.b.lens + OTZ_ENC_DSYM, L.code + OTZ_ENC_DSYM);
+		otz_wave_sync_lds ();
+		OTZ_ENC_MARK (5);
 		// sizes: how many length and distance codes are sent, the run-length tokens, their code
 		u32 hlit = 257, hdist = 1;
 #pragma unroll
 		for (u32 k = 0; k < 5u; k++) {
 			const u32 i = lane + 64u * k;
-			const u64 nz = otz_ballot (i < 286u && L.lens[i] != 0u);
+			const u64 nz = otz_ballot (i < 286u && L.b.lens[i] != 0u);
 			if (nz) {
 				const u32 top = 64u * k + 64u - otz_clz64 (nz);
 				hlit = top > hlit ? top : hlit;
 			}
 		}
 		{
-			const u64 nz = otz_ballot (lane < 30u && L.lens[OTZ_ENC_DSYM + lane] != 0u);
+			const u64 nz = otz_ballot (lane < 30u && L.b.lens[OTZ_ENC_DSYM + lane] != 0u);
 			if (nz) {
 				hdist = 64u - otz_clz64 (nz);
 			}
 		}
 		if (lane < 32u) {
-			L.clhist[lane] = 0;
+			L.b.clhist[lane] = 0;
 		}
-		otz_wave_sync ();
+		otz_wave_sync_lds ();
 		if (lane == 0) {
-			u32 nt = otz_enc_rle_lengths (L, L.lens, hlit, 0);
-			L.n_cltok = otz_enc_rle_lengths (L, L.lens + OTZ_ENC_DSYM, hdist, nt);
+			u32 nt = otz_enc_rle_lengths (L, L.b.lens, hlit, 0);
+			L.b.n_cltok = otz_enc_rle_lengths (L, L.b.lens + OTZ_ENC_DSYM, hdist, nt);
 		}
-		otz_wave_sync ();
-		const u32 n_cltok = L.n_cltok;
+		otz_wave_sync_lds ();
+		const u32 n_cltok = L.b.n_cltok;
 		for (u32 i = lane; i < n_cltok; i += OTZ_ENC_NT) {
-			otz_lds_add (&L.clhist[L.cltok[i] & 31u], 1u);
+			otz_lds_add (&L.b.clhist[L.b.cltok[i] & 31u], 1u);
 		}
-		otz_wave_sync ();
-		otz_enc_build_code<1> (L, L.clhist, 19u, 7u, L.cllens, L.clcode);
-		otz_wave_sync ();
+		otz_wave_sync_lds ();
+		otz_enc_build_code<1> (L, L.b.clhist, 19u, 7u, L.b.cllens, L.b.clcode);
+		otz_wave_sync_lds ();
 		// the code-length code lengths go out in the order of RFC 1951 3.2.7
-		const u32 my_cl = lane < 19u ? L.cllens[otz_cl_order[lane]] : 0u;
+		const u32 my_cl = lane < 19u ? L.b.cllens[otz_cl_order[lane]] : 0u;
 		const u64 clnz = otz_ballot (my_cl != 0u);
 		u32 hclen = clnz ? 64u - otz_clz64 (clnz) : 4u;
 		hclen = hclen < 4u ? 4u : hclen;
@@ -632,19 +779,20 @@ OTZ_DEV u32 otz_deflate_entry(otz_enc_lds &L, const u8 *src, u32 n, u8 *dst, u32
 			} else {
 				fl = 5;
 			}
-			dyn += f * L.lens[i];
+			dyn += f * L.b.lens[i];
 			fix += f * fl;
 		}
 		for (u32 i = lane; i < n_cltok; i += OTZ_ENC_NT) {
-			const u32 t = L.cltok[i] & 31u;
-			dyn += L.cllens[t] + (t == 16u ? 2u : t == 17u ? 3u : t == 18u ? 7u : 0u);
+			const u32 t = L.b.cltok[i] & 31u;
+			dyn += L.b.cllens[t] + (t == 16u ? 2u : t == 17u ? 3u : t == 18u ? 7u : 0u);
 		}
 		dyn = otz_enc_wave_sum (dyn) + 14u + 3u * hclen;
 		fix = otz_enc_wave_sum (fix);
 		const bool use_fixed = fix <= dyn;
+		OTZ_ENC_MARK (6);
 		// ------------------------------------------------------------------ EMIT
 		if (use_fixed) {
-			otz_wave_sync ();
+			otz_wave_sync_lds ();
 			for (u32 i = lane; i < 320u; i += OTZ_ENC_NT) {
 				u32 nb, b;
 				if (i < OTZ_ENC_DSYM) {
@@ -655,7 +803,7 @@ OTZ_DEV u32 otz_deflate_entry(otz_enc_lds &L, const u8 *src, u32 n, u8 *dst, u32
 				}
 				L.code[i] = b | nb << 16;
 			}
-			otz_wave_sync ();
+			otz_wave_sync_lds ();
 			otz_enc_put (L, S, 2u, lane == 0 ? 3u : 0u); // BFINAL = 0, BTYPE = 01
 		} else {
 			// BFINAL = 0, BTYPE = 10, HLIT, HDIST, HCLEN, then the code-length code lengths (3 bits each)
@@ -667,7 +815,7 @@ OTZ_DEV u32 otz_deflate_entry(otz_enc_lds &L, const u8 *src, u32 n, u8 *dst, u32
 				u64 bits = 0;
 				u32 nb = 0;
 				if (i < n_cltok) {
-					const u32 t = L.cltok[i], sym = t & 31u, e = L.clcode[sym];
+					const u32 t = L.b.cltok[i], sym = t & 31u, e = L.b.clcode[sym];
 					nb = e >> 16;
 					bits = (e & 0xFFFFu) | (u64) (t >> 5) << nb;
 					nb += sym == 16u ? 2u : sym == 17u ? 3u : sym == 18u ? 7u : 0u;
@@ -675,23 +823,28 @@ OTZ_DEV u32 otz_deflate_entry(otz_enc_lds &L, const u8 *src, u32 n, u8 *dst, u32
 				otz_enc_put (L, S, bits, nb);
 			}
 		}
+		OTZ_ENC_MARK (7);
+		u32 tnext = lane < ntok ? tok[lane] : 0u;
 		for (u32 b = 0; b < ntok && !S.overflow; b += 64u) {
 			const u32 i = b + lane;
 			u64 bits = 0;
 			u32 nb = 0;
+			const u32 t = tnext;
+			if (i + 64u < ntok) {
+				tnext = tok[i + 64u];
+			}
 			if (i < ntok) {
-				const u32 t = tok[i];
 				if (t & OTZ_TOK_MATCH) {
-					u32 xb, xv;
-					const u32 e = L.code[otz_enc_len_sym (((t >> 16) & 0xFFu) + 3u, &xb, &xv)];
+					const u32 li = (t >> 23) & 31u, ds = (t >> 13) & 31u;
+					const u32 e = L.code[257u + li], e2 = L.code[OTZ_ENC_DSYM + ds];
+					const u32 xb = li < 8u || li == 28u ? 0u : (li >> 2) - 1u, xb2 = ds < 4u ? 0u : (ds >> 1) - 1u;
 					nb = e >> 16;
-					bits = (e & 0xFFFFu) | (u64)xv << nb;
+					bits = (e & 0xFFFFu) | (u64) ((t >> 18) & 31u) << nb;
 					nb += xb;
-					const u32 e2 = L.code[OTZ_ENC_DSYM + otz_enc_dist_sym ((t & 0x7FFFu) + 1u, &xb, &xv)];
 					bits |= (u64) (e2 & 0xFFFFu) << nb;
 					nb += e2 >> 16;
-					bits |= (u64)xv << nb;
-					nb += xb;
+					bits |= (u64) (t & 0x1FFFu) << nb;
+					nb += xb2;
 				} else {
 					const u32 e = L.code[t];
 					nb = e >> 16;
@@ -705,6 +858,13 @@ OTZ_DEV u32 otz_deflate_entry(otz_enc_lds &L, const u8 *src, u32 n, u8 *dst, u32
 			otz_enc_put (L, S, e & 0xFFFFu, lane == 0 ? e >> 16 : 0u);
 		}
 		otz_wave_sync ();
+		if (more) {
+			for (u32 i = lane; i < OTZ_ENC_BUILD_U4; i += OTZ_ENC_NT) {
+				*reinterpret_cast<otz_u4 *> (&L.head[4u * i]) = otz_ld16_aligned (tok + OTZ_ENC_BLOCK + 4u * i);
+			}
+			otz_wave_sync_lds ();
+		}
+		OTZ_ENC_MARK (8);
 	}
 	// the final block: stored, empty (BFINAL = 1, BTYPE = 00, pad to a byte, LEN = 0, NLEN = 0xFFFF)
 	otz_enc_put (L, S, 1u, lane == 0 ? 3u : 0u);
@@ -720,6 +880,12 @@ OTZ_DEV u32 otz_deflate_entry(otz_enc_lds &L, const u8 *src, u32 n, u8 *dst, u32
 		for (u32 i = lane; i < tail; i += OTZ_ENC_NT) {
 			S.dst[S.out_pos + i] = ob[i];
 		}
+	}
+	if (PROF && prof && lane == 0) {
+		for (u32 i = 0; i < 9u; i++) {
+			prof[i] = pc[i];
+		}
+		prof[15] = otz_cycles () - pstart;
 	}
 	return S.overflow ? ~0u : S.out_pos + tail;
 }
@@ -924,7 +1090,8 @@ OTZ_DEV u32 otz_frame_entry(u32 method, const u8 *in, u32 n, u8 *out, u32 cap) {
 	return (u32)total;
 }
 
-OTZ_DEV void otz_encode_entry(otz_enc_lds &L, const u8 *src, u8 *dst, const ozg_enc_entry &e, ozg_enc_result *res, u32 *tok) {
+template <bool PROF>
+OTZ_DEV void otz_encode_entry(otz_enc_lds &L, const u8 *src, u8 *dst, const ozg_enc_entry &e, ozg_enc_result *res, u32 *tok, u64 *prof = nullptr) {
 	const u32 lane = otz_tid ();
 	const u8 *in = src + e.src_off;
 	u8 *out = dst + e.dst_off;
@@ -939,6 +1106,11 @@ OTZ_DEV void otz_encode_entry(otz_enc_lds &L, const u8 *src, u8 *dst, const ozg_
 		}
 		return;
 	}
+	// (one call site: the encoder is by far the largest function of the kernel)
+	u32 dcs = 0;
+	if (e.method == OZG_METHOD_DEFLATE && e.src_size > 0) {
+		dcs = otz_deflate_entry<PROF> (L, in, e.src_size, out, e.dst_cap, tok, prof);
+	}
 	if (codec_only) {
 		// codec-level call (deflate() of the z_stream seam): the stream itself is the
 		// product, there is no "not smaller -> STORE" rule at this level (ref deflate() has none)
@@ -948,7 +1120,7 @@ OTZ_DEV void otz_encode_entry(otz_enc_lds &L, const u8 *src, u8 *dst, const ozg_
 		} else if (e.method != OZG_METHOD_DEFLATE) {
 			cs = otz_frame_entry (e.method, in, e.src_size, out, e.dst_cap);
 		} else if (e.src_size > 0) {
-			cs = otz_deflate_entry (L, in, e.src_size, out, e.dst_cap, tok);
+			cs = dcs;
 		} else {
 			cs = 5; // an empty final stored block
 			if (lane == 0 && e.dst_cap >= 5u) {
@@ -968,7 +1140,7 @@ OTZ_DEV void otz_encode_entry(otz_enc_lds &L, const u8 *src, u8 *dst, const ozg_
 		return;
 	}
 	if (e.method == OZG_METHOD_DEFLATE && e.src_size > 0) {
-		u32 cs = otz_deflate_entry (L, in, e.src_size, out, e.dst_cap, tok);
+		const u32 cs = dcs;
 		stored = cs >= e.src_size; // did not fit, or not smaller: ref otezip.c:846-850
 		otz_wave_sync ();          // the encoder's last stores land before a STORE copy reuses dst
 		if (!stored && lane == 0) {

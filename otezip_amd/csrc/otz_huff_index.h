@@ -89,18 +89,6 @@ struct otz_k1_lds {
 
 // ------------------------------------------------------------------ wave helpers
 
-OTZ_DEV u32 otz_wave_scan_incl(u32 v) {
-	const u32 lane = otz_lane ();
-#pragma unroll
-	for (u32 d = 1; d < 64; d <<= 1) {
-		u32 o = otz_shfl_up (v, d);
-		if (lane >= d) {
-			v += o;
-		}
-	}
-	return v;
-}
-
 // 16 bytes of the entry at byte offset off (may be negative or run past the end: zeros there)
 OTZ_DEV otz_u4 otz_k1_ld16(const u8 *in, u32 n_in, int64_t off) {
 	if (off >= 0 && off + 16 <= (int64_t)n_in) {

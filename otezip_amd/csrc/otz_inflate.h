@@ -150,11 +150,6 @@ struct otz_job {
 
 // ------------------------------------------------------------------ helpers
 
-#ifdef OTZ_SIMT_EMU
-OTZ_DEV u64 otz_cycles() { return 0; }
-#else
-OTZ_DEV u64 otz_cycles() { return __builtin_readcyclecounter (); }
-#endif
 // work-item 0 charges the cycles since the previous mark to `phase`
 #define OTZ_MARK(L, J, phase) \
 	do { \
@@ -303,13 +298,7 @@ OTZ_DEV otz_tok otz_decode_adv(const otz_inflate_lds &L, otz_win &W, u32 pos) {
 // Inclusive prefix sum over the workgroup; *total gets the sum. Uniform control flow.
 OTZ_DEV u32 otz_block_scan_incl(u32 v, u32 *scratch, u32 *total) {
 	u32 lane = otz_lane ();
-#pragma unroll
-	for (u32 d = 1; d < 64; d <<= 1) {
-		u32 o = otz_shfl_up (v, d);
-		if (lane >= d) {
-			v += o;
-		}
-	}
+	v = otz_wave_scan_incl (v);
 	otz_sync ();
 	if (lane == 63u) {
 		scratch[otz_wave ()] = v;

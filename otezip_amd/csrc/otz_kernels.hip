@@ -185,12 +185,12 @@ otz_crc32_kernel(const u8 *buf, const u64 *off, const u32 *len, u32 *crc, u32 n)
 	}
 }
 
-// DEFLATE encode / STORE of n independent buffers: one wavefront per buffer (26 KB LDS).  The grid is
+// DEFLATE encode / STORE of n independent buffers: one wavefront per buffer (20 KB LDS).  The grid is
 // persistent -- as many wavefronts as fit the chip, each taking the next buffer off a counter -- so
 // that the token scratch (OTZ_ENC_TOK_WORDS words per wavefront) is sized by the chip, not the batch.
-extern "C" __global__ void __launch_bounds__ (64)
-otz_encode_kernel(const u8 *src, u8 *dst, const ozg_enc_entry *entries, ozg_enc_result *results, u32 n, u64 src_len, u64 dst_len,
-	u32 *tok, u32 *cursor) {
+template <bool PROF>
+__device__ __forceinline__ void otz_encode_grid(const u8 *src, u8 *dst, const ozg_enc_entry *entries, ozg_enc_result *results, u32 n, u64 src_len,
+	u64 dst_len, u32 *tok, u32 *cursor, u64 *prof) {
 	extern __shared__ __attribute__ ((aligned (16))) u8 otz_smem[];
 	otz_enc_lds &L = *reinterpret_cast<otz_enc_lds *> (otz_smem);
 	u32 *my_tok = tok + (size_t)blockIdx.x * OTZ_ENC_TOK_WORDS;
@@ -214,9 +214,22 @@ otz_encode_kernel(const u8 *src, u8 *dst, const ozg_enc_entry *entries, ozg_enc_
 			}
 			continue;
 		}
-		otz_encode_entry (L, src, dst, e, &results[i], my_tok);
+		otz_encode_entry<PROF> (L, src, dst, e, &results[i], my_tok, PROF && prof ? prof + 32ull * i : nullptr);
 		otz_wave_sync ();
 	}
+}
+
+extern "C" __global__ void __launch_bounds__ (64)
+otz_encode_kernel(const u8 *src, u8 *dst, const ozg_enc_entry *entries, ozg_enc_result *results, u32 n, u64 src_len, u64 dst_len,
+	u32 *tok, u32 *cursor, u64 *prof) {
+	otz_encode_grid<false> (src, dst, entries, results, n, src_len, dst_len, tok, cursor, prof);
+}
+
+// diagnostic build of the same kernel with the per-phase cycle counters (tools/prof_encode.py)
+extern "C" __global__ void __launch_bounds__ (64)
+otz_encode_prof_kernel(const u8 *src, u8 *dst, const ozg_enc_entry *entries, ozg_enc_result *results, u32 n, u64 src_len, u64 dst_len,
+	u32 *tok, u32 *cursor, u64 *prof) {
+	otz_encode_grid<true> (src, dst, entries, results, n, src_len, dst_len, tok, cursor, prof);
 }
 
 // CRC-32 of every input buffer of an encode batch (ref src/lib/otezip.c:1124)
@@ -264,7 +277,6 @@ namespace {
 
 constexpr int MAX_DEV = 16;
 constexpr int N_SLOTS = 3; // asynchronous staged batches in flight per device
-constexpr u32 ENC_GRID = 256u * 6u; // encode wavefronts resident on the chip (26 KB of LDS each)
 
 std::mutex g_mu; // contexts, their buffers and slots
 u32 g_chunks = 1; // chunks of a large DEFLATE batch on two internal streams (OTEZIP_GPU_CHUNKS; 0 = cut at a whole number of index-kernel generations): neither measured faster than one launch pair (4.13 ms; 4 chunks 4.43, generation cut 4.14), kept for experiments
@@ -318,6 +330,7 @@ namespace {
 struct dev_ctx {
 	bool ready = false;
 	u32 gen = 4096; // index wavefronts resident on the chip at once
+	u32 enc_grid = 2048; // encode wavefronts resident on the chip at once (LDS-bound)
 	staging stage; // synchronous host entry points
 	workspace ws;
 	ozg_job slots[N_SLOTS];
@@ -591,10 +604,15 @@ int ozg_init(int device) {
 			(int)sizeof (otz_copy_lds)));
 		OZG_HIP (hipFuncSetAttribute ((const void *)otz_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
 			(int)sizeof (otz_enc_lds)));
+		OZG_HIP (hipFuncSetAttribute ((const void *)otz_encode_prof_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+			(int)sizeof (otz_enc_lds)));
 		int cus = 256, per_cu = 16;
 		(void)hipDeviceGetAttribute (&cus, hipDeviceAttributeMultiprocessorCount, device);
 		(void)hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu, otz_index_kernel, 64, sizeof (otz_k1_lds));
 		g_dev[device].gen = (u32) (cus > 0 ? cus : 256) * (u32) (per_cu > 0 ? per_cu : 16);
+		per_cu = 8;
+		(void)hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu, otz_encode_kernel, 64, sizeof (otz_enc_lds));
+		g_dev[device].enc_grid = (u32) (cus > 0 ? cus : 256) * (u32) (per_cu > 0 ? per_cu : 8);
 		g_dev[device].ready = true;
 	}
 	if (const char *c = getenv ("OTEZIP_GPU_CHUNKS")) {
@@ -857,6 +875,7 @@ int ozg_encode_batch_device(const void *d_src, uint64_t src_len, void *d_dst, ui
 	}
 	hipStream_t s = (hipStream_t)stream;
 	workspace &ws = C->ws;
+	const u32 ENC_GRID = C->enc_grid;
 	const u32 grid = n < ENC_GRID ? n : ENC_GRID;
 	if (!ws.enc_done) {
 		OZG_HIP (hipEventCreateWithFlags (&ws.enc_done, hipEventDisableTiming));
@@ -876,8 +895,8 @@ int ozg_encode_batch_device(const void *d_src, uint64_t src_len, void *d_dst, ui
 		OZG_HIP (hipStreamWaitEvent (s, ws.enc_done, 0)); // the scratch is shared between streams
 	}
 	OZG_HIP (hipMemsetAsync (ws.enc_cursor, 0, 4, s));
-	hipLaunchKernelGGL (otz_encode_kernel, dim3 (grid), dim3 (64), sizeof (otz_enc_lds), s, (const u8 *)d_src, (u8 *)d_dst,
-		d_entries, d_results, n, (u64)src_len, (u64)dst_len, ws.enc_tok, ws.enc_cursor);
+	hipLaunchKernelGGL (g_prof ? otz_encode_prof_kernel : otz_encode_kernel, dim3 (grid), dim3 (64), sizeof (otz_enc_lds), s, (const u8 *)d_src,
+		(u8 *)d_dst, d_entries, d_results, n, (u64)src_len, (u64)dst_len, ws.enc_tok, ws.enc_cursor, g_prof);
 	OZG_HIP (hipGetLastError ());
 	OZG_HIP (hipEventRecord (ws.enc_done, s));
 	ws.enc_busy = true;

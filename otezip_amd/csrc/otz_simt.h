@@ -46,11 +46,34 @@ OTZ_DEV void otz_wave_sync() {
 	__builtin_amdgcn_wave_barrier ();
 }
 
+// Same, when only LDS traffic has to be ordered: the LDS pipeline executes one wavefront's DS
+// instructions in issue order, so nothing has to drain -- the compiler just must not move them.
+OTZ_DEV void otz_wave_sync_lds() {
+	asm volatile ("" ::: "memory");
+	__builtin_amdgcn_wave_barrier ();
+	asm volatile ("" ::: "memory");
+}
+
 // wave64 cross-lane
 OTZ_DEV u64 otz_ballot(bool p) { return __ballot (p); }
 OTZ_DEV u32 otz_shfl_up(u32 v, u32 d) { return (u32)__shfl_up ((int)v, d, 64); }
 OTZ_DEV u32 otz_shfl(u32 v, u32 src) { return (u32)__shfl ((int)v, (int)src, 64); }
 OTZ_DEV u32 otz_shfl_xor(u32 v, u32 m) { return (u32)__shfl_xor ((int)v, (int)m, 64); }
+// DPP cross-lane moves: VALU only, no trip through the LDS crossbar (__shfl_up is a ds_bpermute_b32,
+// ~100 cycles of latency each; a six-step scan built from it is 600+ cycles of dependent waiting).
+// value of lane - 1 (lane 0: fill) / of lane + 1 (lane 63: fill): v_mov_b32 wave_shr:1 / wave_shl:1
+OTZ_DEV u32 otz_lane_up1(u32 v, u32 fill) { return (u32)__builtin_amdgcn_update_dpp ((int)fill, (int)v, 0x138, 0xf, 0xf, false); }
+OTZ_DEV u32 otz_lane_down1(u32 v, u32 fill) { return (u32)__builtin_amdgcn_update_dpp ((int)fill, (int)v, 0x130, 0xf, 0xf, false); }
+// inclusive prefix sum over the wavefront: row_shr 1/2/4/8 inside the rows of 16, then row_bcast:15 / :31
+OTZ_DEV u32 otz_wave_scan_incl(u32 v) {
+	v += (u32)__builtin_amdgcn_update_dpp (0, (int)v, 0x111, 0xf, 0xf, true);
+	v += (u32)__builtin_amdgcn_update_dpp (0, (int)v, 0x112, 0xf, 0xf, true);
+	v += (u32)__builtin_amdgcn_update_dpp (0, (int)v, 0x114, 0xf, 0xf, true);
+	v += (u32)__builtin_amdgcn_update_dpp (0, (int)v, 0x118, 0xf, 0xf, true);
+	v += (u32)__builtin_amdgcn_update_dpp (0, (int)v, 0x142, 0xa, 0xf, false);
+	v += (u32)__builtin_amdgcn_update_dpp (0, (int)v, 0x143, 0xc, 0xf, false);
+	return v;
+}
 // value of lane `src`, where src is the same in every lane: v_readlane_b32 (no LDS round trip)
 OTZ_DEV u32 otz_readlane(u32 v, u32 src) { return (u32)__builtin_amdgcn_readlane ((int)v, (int)__builtin_amdgcn_readfirstlane ((int)src)); }
 // a value known to be the same in every lane, moved to a scalar register
@@ -80,6 +103,9 @@ OTZ_DEV void otz_backoff() { __builtin_amdgcn_s_sleep (2); }
 // the other workgroup on the CU.
 OTZ_DEV void otz_set_priority_high() { __builtin_amdgcn_s_setprio (2); }
 OTZ_DEV void otz_set_priority_normal() { __builtin_amdgcn_s_setprio (0); }
+
+// shader clock, for the diagnostic phase counters only
+OTZ_DEV u64 otz_cycles() { return __builtin_readcyclecounter (); }
 
 OTZ_DEV u32 otz_popc(u32 v) { return (u32)__popc (v); }
 OTZ_DEV u32 otz_popc64(u64 v) { return (u32)__popcll (v); }

@@ -56,7 +56,7 @@ void *thread_main(void *p) {
 	otz_emu_self.tid = a->tid;
 	otz_emu_self.blk = a->blk;
 	if (a->phase == 3) {
-		otz_encode_entry (*(otz_enc_lds *)a->lds, a->src, a->dst, *a->enc_e, a->enc_r, a->enc_tok);
+		otz_encode_entry<false> (*(otz_enc_lds *)a->lds, a->src, a->dst, *a->enc_e, a->enc_r, a->enc_tok);
 	} else if (a->phase == 1) {
 		otz_run_index<false> (*(otz_k1_lds *)a->lds, a->src, a->dst, *a->e, a->lim, a->head, a->region, a->region_bytes);
 	} else if (a->phase == 2) {

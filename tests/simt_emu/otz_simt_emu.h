@@ -145,6 +145,25 @@ OTZ_DEV u32 otz_shfl_up(u32 v, u32 d) {
 	return r;
 }
 OTZ_DEV u32 otz_shfl_xor(u32 v, u32 m) { return otz_shfl (v, otz_lane () ^ m); }
+OTZ_DEV u32 otz_lane_up1(u32 v, u32 fill) {
+	const u32 l = otz_lane (), r = otz_shfl (v, l ? l - 1u : 0u);
+	return l ? r : fill;
+}
+OTZ_DEV u32 otz_lane_down1(u32 v, u32 fill) {
+	const u32 l = otz_lane (), r = otz_shfl (v, l < 63u ? l + 1u : 63u);
+	return l < 63u ? r : fill;
+}
+OTZ_DEV u32 otz_wave_scan_incl(u32 v) {
+	const u32 l = otz_lane ();
+	for (u32 d = 1; d < 64; d <<= 1) {
+		const u32 o = otz_shfl (v, l >= d ? l - d : l);
+		if (l >= d) {
+			v += o;
+		}
+	}
+	return v;
+}
+OTZ_DEV void otz_wave_sync_lds() { otz_wave_sync (); }
 OTZ_DEV u32 otz_readlane(u32 v, u32 src) { return otz_shfl (v, src); }
 OTZ_DEV u32 otz_uniform(u32 v) { return v; }
 
@@ -168,6 +187,7 @@ OTZ_DEV void otz_fence_acquire() { __atomic_thread_fence (__ATOMIC_ACQUIRE); }
 OTZ_DEV void otz_set_priority_high() {}
 OTZ_DEV void otz_set_priority_normal() {}
 
+OTZ_DEV u64 otz_cycles() { return 0; }
 OTZ_DEV u32 otz_popc(u32 v) { return (u32)__builtin_popcount (v); }
 OTZ_DEV u32 otz_popc64(u64 v) { return (u32)__builtin_popcountll (v); }
 OTZ_DEV u32 otz_brev(u32 v) {

@@ -1,12 +1,16 @@
 #!/bin/bash
 # SQ counter passes over bench.py (each --pmc set in its own run, kernel-trace only), reduced to
-# one JSON by tools/sq_summary.py.  Usage (GPU box): tools/sq_counters.sh <tag>
+# one JSON by tools/sq_summary.py.  Usage (GPU box): tools/sq_counters.sh <tag> [program args...]
+# (default program: bench.py --steps 3 --warmup 1 --no-cpu-baseline; e.g. `tools/sq_counters.sh enc tools/prof_encode.py 10000`)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 tag=${1:-sq}
+shift
+if [ $# -eq 0 ]; then set -- bench.py --steps 3 --warmup 1 --no-cpu-baseline; fi
+prog=("$@")
 run() { # name counters...
 	local name=$1; shift
 	echo "[sq] pass ${name}: $@"
-	timeout -k 10 150 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc_${tag}_${name} -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_${tag}_${name}.log 2>&1 || { echo "[sq] pass ${name} failed"; tail -3 gpurun_out/pmc_${tag}_${name}.log; exit 1; }
+	timeout -k 10 150 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc_${tag}_${name} -- python3 "${prog[@]}" > gpurun_out/pmc_${tag}_${name}.log 2>&1 || { echo "[sq] pass ${name} failed"; tail -3 gpurun_out/pmc_${tag}_${name}.log; exit 1; }
 }
 # (at most four SQ counters per pass: a seven-counter pass hung on this pool)
 run busy SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS
