@@ -257,6 +257,13 @@ OTZ_DEV u32 otz_enc_wave_sum(u32 v) {
 	return v;
 }
 
+struct otz_false_c {
+	static constexpr bool value = false;
+};
+struct otz_true_c {
+	static constexpr bool value = true;
+};
+
 OTZ_CONST_TABLE u8 otz_cl_order[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
 
 // ---------------------------------------------------------------- Huffman code construction
@@ -286,60 +293,94 @@ OTZ_DEV void otz_enc_build_code(otz_enc_lds &L, u32 *freq, u32 nsym, u32 limit, 
 		m = 2;
 		otz_wave_sync_lds ();
 	}
-	// rank by (weight, symbol)
-	u32 key[NCH], rk[NCH];
-#pragma unroll
-	for (u32 k = 0; k < NCH; k++) {
-		const u32 i = lane + 64u * k;
-		const u32 f = i < nsym ? freq[i] : 0u;
-		key[k] = f ? (f << 9 | i) : 0u;
-		rk[k] = 0;
-		if (i < nsym) {
-			lens[i] = 0;
-		}
-	}
-	for (u32 j = 0; j < nsym; j++) {
-		const u32 fj = freq[j];
-		const u32 kj = fj ? (fj << 9 | j) : 0xFFFFFFFFu;
+	// the symbols in use, as keys (weight << 9 | symbol), packed in symbol order (L.b.iw is free until the merge)
+	{
+		u32 before = 0;
 #pragma unroll
 		for (u32 k = 0; k < NCH; k++) {
-			rk[k] += kj < key[k] ? 1u : 0u;
+			const u32 i = lane + 64u * k;
+			const u32 f = i < nsym ? freq[i] : 0u;
+			const u64 bal = otz_ballot (f != 0u);
+			if (f) {
+				L.b.iw[before + otz_popc64 (bal & ((1ull << lane) - 1ull))] = f << 9 | i;
+			}
+			if (i < nsym) {
+				lens[i] = 0;
+			}
+			before += otz_popc64 (bal);
 		}
-	}
-#pragma unroll
-	for (u32 k = 0; k < NCH; k++) {
-		if (key[k]) {
-			L.b.sw[rk[k]] = key[k] >> 9;
-			L.b.ssym[rk[k]] = (u16) (key[k] & 511u);
-		}
+		m = before;
 	}
 	if (lane < 16u) {
 		L.b.blc[lane] = 0;
 	}
 	otz_wave_sync_lds ();
-	// two-queue merge: leaves in ascending order, internal nodes in creation order (also ascending)
+	// rank by (weight, symbol): every key against all m
+	{
+		u32 key[NCH], rk[NCH];
+#pragma unroll
+		for (u32 k = 0; k < NCH; k++) {
+			const u32 c = lane + 64u * k;
+			key[k] = c < m ? L.b.iw[c] : 0u;
+			rk[k] = 0;
+		}
+#pragma unroll 4
+		for (u32 j = 0; j < m; j++) {
+			const u32 kj = L.b.iw[j];
+#pragma unroll
+			for (u32 k = 0; k < NCH; k++) {
+				rk[k] += kj < key[k] ? 1u : 0u;
+			}
+		}
+#pragma unroll
+		for (u32 k = 0; k < NCH; k++) {
+			if (key[k]) {
+				L.b.sw[rk[k]] = key[k] >> 9;
+				L.b.ssym[rk[k]] = (u16) (key[k] & 511u);
+			}
+		}
+	}
+	otz_wave_sync_lds ();
+	// two-queue merge: leaves in ascending order, internal nodes in creation order (also ascending);
+	// the next two of each queue are kept in registers, so a step waits for LDS once
 	if (lane == 0) {
+		const u32 INF = 0xFFFFFFFFu;
 		u32 li = 0, ih = 0;
-		u32 lw = L.b.sw[0], inw = 0xFFFFFFFFu;
+		u32 l0 = L.b.sw[0], l1 = L.b.sw[1], i0 = INF, i1 = INF;
 		for (u32 k = 0; k + 1u < m; k++) {
-			u32 sum = 0;
-			for (u32 t = 0; t < 2u; t++) {
-				if (li < m && lw <= inw) {
-					sum += lw;
-					L.b.lpar[li] = (u16)k;
-					li++;
-					lw = li < m ? L.b.sw[li] : 0xFFFFFFFFu;
+			u32 sum, nl, ni;
+			if (l0 <= i0) { // (a leaf wins a tie)
+				if (l1 <= i0) {
+					sum = l0 + l1;
+					nl = 2;
+					ni = 0;
 				} else {
-					sum += inw;
-					L.b.ipar[ih] = (u16)k;
-					ih++;
-					inw = ih < k ? L.b.iw[ih] : 0xFFFFFFFFu;
+					sum = l0 + i0;
+					nl = 1;
+					ni = 1;
 				}
+			} else if (l0 <= i1) {
+				sum = i0 + l0;
+				nl = 1;
+				ni = 1;
+			} else {
+				sum = i0 + i1;
+				nl = 0;
+				ni = 2;
 			}
+			for (u32 t = 0; t < nl; t++) {
+				L.b.lpar[li + t] = (u16)k;
+			}
+			for (u32 t = 0; t < ni; t++) {
+				L.b.ipar[ih + t] = (u16)k;
+			}
+			li += nl;
+			ih += ni;
 			L.b.iw[k] = sum;
-			if (ih == k) {
-				inw = sum; // the queue of internal nodes was empty: the new node is its head
-			}
+			l0 = li < m ? L.b.sw[li] : INF;
+			l1 = li + 1u < m ? L.b.sw[li + 1u] : INF;
+			i0 = ih < k ? L.b.iw[ih] : (ih == k ? sum : INF);
+			i1 = ih + 1u < k ? L.b.iw[ih + 1u] : (ih + 1u == k ? sum : INF);
 		}
 	}
 	otz_wave_sync_lds ();
@@ -437,15 +478,19 @@ OTZ_DEV void otz_enc_build_code(otz_enc_lds &L, u32 *freq, u32 nsym, u32 limit, 
 }
 
 // Run-length tokens (code-length alphabet, RFC 1951 3.2.7) for lens[0..n), appended to L.b.cltok; one lane.
+// lens is 8-byte aligned and readable up to the next multiple of eight: eight lengths per LDS read.
 OTZ_DEV u32 otz_enc_rle_lengths(otz_enc_lds &L, const u8 *lens, u32 n, u32 nt) {
-	u32 i = 0;
-	while (i < n) {
-		const u32 v = lens[i];
-		u32 r = 1;
-		while (i + r < n && lens[i + r] == v) {
-			r++;
+	u32 v = 0x100u, r = 0; // the run so far
+	u64 w = 0;
+	for (u32 i = 0; i <= n; i++) {
+		if ((i & 7u) == 0u && i < n) {
+			w = otz_ld64u (lens + i);
 		}
-		i += r;
+		const u32 c = i < n ? (u32) (w >> (8u * (i & 7u))) & 0xFFu : 0x200u;
+		if (c == v) {
+			r++;
+			continue;
+		}
 		if (v == 0u) {
 			while (r >= 11u) {
 				const u32 t = r < 138u ? r : 138u;
@@ -456,7 +501,7 @@ OTZ_DEV u32 otz_enc_rle_lengths(otz_enc_lds &L, const u8 *lens, u32 n, u32 nt) {
 				L.b.cltok[nt++] = (u16) (17u | (r - 3u) << 5);
 				r = 0;
 			}
-		} else {
+		} else if (r > 0u) {
 			L.b.cltok[nt++] = (u16)v;
 			r--;
 			while (r >= 3u) {
@@ -469,6 +514,8 @@ OTZ_DEV u32 otz_enc_rle_lengths(otz_enc_lds &L, const u8 *lens, u32 n, u32 nt) {
 			L.b.cltok[nt++] = (u16)v;
 			r--;
 		}
+		v = c;
+		r = 1;
 	}
 	return nt;
 }
@@ -493,7 +540,7 @@ OTZ_DEV u32 otz_deflate_entry(otz_enc_lds &L, const u8 *src, u32 n, u8 *dst, u32
 	u64 pc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 	u64 plast = PROF ? otz_cycles () : 0;
 	const u64 pstart = plast;
-	const u64 lt_mask = (1ull << lane) - 1ull;
+	const u32 lane4 = lane << 2;
 	otz_enc_state S;
 	S.bitpos = 0;
 	S.out_pos = 0;
@@ -543,13 +590,16 @@ OTZ_DEV u32 otz_deflate_entry(otz_enc_lds &L, const u8 *src, u32 n, u8 *dst, u32
 				}
 			}
 			otz_wave_sync_lds ();
+			// (TAIL: the iteration may reach the end of the buffer; all others run without the end checks)
+			auto iteration = [&](auto tail_c) {
+			constexpr bool TAIL = decltype (tail_c)::value;
 			u32 pos[OTZ_ENC_U], h[OTZ_ENC_U], c[OTZ_ENC_U], len[OTZ_ENC_U], dist[OTZ_ENC_U];
 			u64 own[OTZ_ENC_U];
 			bool can[OTZ_ENC_U];
 #pragma unroll
 			for (u32 u = 0; u < OTZ_ENC_U; u++) {
 				pos[u] = p + 64u * u + lane;
-				can[u] = pos[u] + OTZ_ENC_MINLEN <= n;
+				can[u] = !TAIL || pos[u] + OTZ_ENC_MINLEN <= n;
 				own[u] = otz_enc_ld8 (L, pos[u]);
 				h[u] = ((u32)own[u] * 0x9E3779B1u) >> (32u - OTZ_ENC_HBITS);
 			}
@@ -575,7 +625,7 @@ OTZ_DEV u32 otz_deflate_entry(otz_enc_lds &L, const u8 *src, u32 n, u8 *dst, u32
 			bool any = false;
 #pragma unroll
 			for (u32 u = 0; u < OTZ_ENC_U; u++) {
-				maxlen[u] = n - pos[u] < 258u ? n - pos[u] : 258u;
+				maxlen[u] = TAIL && n - pos[u] < 258u ? n - pos[u] : 258u;
 				const bool open = can[u] && 64u * u + lane >= skip;
 				const u32 reach = pos[u] < OTZ_ENC_MAXDIST ? pos[u] : OTZ_ENC_MAXDIST; // the farthest a match may lie back
 #pragma unroll
@@ -641,27 +691,30 @@ OTZ_DEV u32 otz_deflate_entry(otz_enc_lds &L, const u8 *src, u32 n, u8 *dst, u32
 				R[u] = 1ull << lane;
 			}
 #if !OTZ_ENC_WALK
+			// J is kept premultiplied by four (ds_bpermute takes byte addresses).  A lane whose chain
+			// has left the step reads ITSELF from then on, which changes nothing: no selects.
 			// (the first round needs no mask from the other lane: one hop reaches J itself)
 #pragma unroll
 			for (u32 u = 0; u < OTZ_ENC_U; u++) {
-				const u32 Jn = otz_shfl (J[u], J[u] & 63u);
-				if (J[u] < 64u) {
-					R[u] |= 1ull << J[u];
-					J[u] = Jn;
-				}
+				const bool in = J[u] < 64u;
+				R[u] |= in ? 1ull << J[u] : 0ull;
+				J[u] <<= 2;
+				J[u] = otz_bpermute4 (in ? J[u] : lane4, J[u]);
 			}
 #pragma unroll
 			for (u32 k = 1; k < 6u; k++) {
 #pragma unroll
 				for (u32 u = 0; u < OTZ_ENC_U; u++) {
-					const u32 from = J[u] & 63u;
-					const u32 Jn = otz_shfl (J[u], from);
-					const u32 Rlo = otz_shfl ((u32)R[u], from), Rhi = otz_shfl ((u32) (R[u] >> 32), from);
-					if (J[u] < 64u) {
-						R[u] |= (u64)Rhi << 32 | Rlo;
-						J[u] = Jn;
-					}
+					const u32 from = J[u] < 256u ? J[u] : lane4;
+					const u32 Jn = otz_bpermute4 (from, J[u]);
+					const u32 Rlo = otz_bpermute4 (from, (u32)R[u]), Rhi = otz_bpermute4 (from, (u32) (R[u] >> 32));
+					R[u] |= (u64)Rhi << 32 | Rlo;
+					J[u] = Jn;
 				}
+			}
+#pragma unroll
+			for (u32 u = 0; u < OTZ_ENC_U; u++) {
+				J[u] >>= 2;
 			}
 #endif
 			OTZ_ENC_MARK (2);
@@ -671,10 +724,10 @@ OTZ_DEV u32 otz_deflate_entry(otz_enc_lds &L, const u8 *src, u32 n, u8 *dst, u32
 					skip -= 64u; // the whole step lies inside the previous match
 					continue;
 				}
-				if (p + 64u * u >= n) {
+				if (TAIL && p + 64u * u >= n) {
 					break;
 				}
-				const u32 left = n - (p + 64u * u), lim = left < 64u ? left : 64u;
+				const u32 left = n - (p + 64u * u), lim = TAIL && left < 64u ? left : 64u;
 #if OTZ_ENC_WALK
 				u64 sel = 0;
 				u32 cur = skip;
@@ -702,9 +755,15 @@ OTZ_DEV u32 otz_deflate_entry(otz_enc_lds &L, const u8 *src, u32 n, u8 *dst, u32
 						t = (u32)own[u] & 0xFFu;
 						otz_lds_add (&L.hist[t], 1u);
 					}
-					tok[ntok + otz_popc64 (sel & lt_mask)] = t;
+					tok[ntok + otz_mbcnt (sel)] = t;
 				}
 				ntok += otz_popc64 (sel);
+			}
+			};
+			if (p + OTZ_ENC_STEP + 258u + 8u <= n) {
+				iteration (otz_false_c ());
+			} else {
+				iteration (otz_true_c ());
 			}
 			OTZ_ENC_MARK (3);
 		}

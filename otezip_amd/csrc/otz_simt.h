@@ -74,6 +74,11 @@ OTZ_DEV u32 otz_wave_scan_incl(u32 v) {
 	v += (u32)__builtin_amdgcn_update_dpp (0, (int)v, 0x143, 0xc, 0xf, false);
 	return v;
 }
+// value of the lane whose number * 4 is byte_addr (ds_bpermute_b32 takes a byte address: callers that
+// keep lane numbers premultiplied save the shift __shfl would add)
+OTZ_DEV u32 otz_bpermute4(u32 byte_addr, u32 v) { return (u32)__builtin_amdgcn_ds_bpermute ((int)byte_addr, (int)v); }
+// number of set bits of mask below this lane's own bit: v_mbcnt_lo + v_mbcnt_hi
+OTZ_DEV u32 otz_mbcnt(u64 mask) { return __builtin_amdgcn_mbcnt_hi ((u32) (mask >> 32), __builtin_amdgcn_mbcnt_lo ((u32)mask, 0u)); }
 // value of lane `src`, where src is the same in every lane: v_readlane_b32 (no LDS round trip)
 OTZ_DEV u32 otz_readlane(u32 v, u32 src) { return (u32)__builtin_amdgcn_readlane ((int)v, (int)__builtin_amdgcn_readfirstlane ((int)src)); }
 // a value known to be the same in every lane, moved to a scalar register

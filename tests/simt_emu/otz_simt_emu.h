@@ -164,6 +164,8 @@ OTZ_DEV u32 otz_wave_scan_incl(u32 v) {
 	return v;
 }
 OTZ_DEV void otz_wave_sync_lds() { otz_wave_sync (); }
+OTZ_DEV u32 otz_bpermute4(u32 byte_addr, u32 v) { return otz_shfl (v, (byte_addr >> 2) & 63u); }
+OTZ_DEV u32 otz_mbcnt(u64 mask) { return (u32)__builtin_popcountll (mask & ((1ull << otz_lane ()) - 1ull)); }
 OTZ_DEV u32 otz_readlane(u32 v, u32 src) { return otz_shfl (v, src); }
 OTZ_DEV u32 otz_uniform(u32 v) { return v; }
 
