@@ -44,6 +44,43 @@ def test_kernel_body_under_emulation():
         assert size / mine >= 0.98 * (size / ref_size), (seed, size, mine, ref_size)
 
 
+def _skewed(n, seed, nsym=40):
+    """Bytes whose frequencies are Fibonacci numbers (as many terms as fit n, at most nsym), in random
+    order: with 17 or more terms the Huffman tree of the literals is deeper than 15, so the length
+    limit of the code construction has to act."""
+    import random
+    r = random.Random(seed)
+    fib = [1, 1]
+    while len(fib) < nsym and sum(fib) + fib[-1] + fib[-2] <= n:
+        fib.append(fib[-1] + fib[-2])
+    pool = bytearray()
+    for i, f in enumerate(fib):
+        pool += bytes([i * 5 % 251]) * f
+    pool += bytes([(len(fib) - 1) * 5 % 251]) * (n - len(pool))
+    lst = list(pool)
+    r.shuffle(lst)
+    return bytes(lst)
+
+
+def _mixed_cases():
+    import random
+    r = random.Random(5)
+    return [_skewed(60000, 1), _skewed(20000, 2, 30), corpus.gen_text(31, 140000),            # three blocks
+            bytes(r.randrange(256) for _ in range(3000)) + corpus.gen_text(32, 3000),          # stored-looking + text
+            b"".join(bytes([r.randrange(3)]) * r.randint(1, 400) for _ in range(600)),         # long runs (len 258, dist 1)
+            bytes(range(256)) * 40, corpus.gen_text(33, 65536 + 7), corpus.gen_text(34, 65535),
+            corpus.gen_text(35, 255), corpus.gen_text(36, 257), b"ab" * 40000, os.urandom(300) * 50]
+
+
+def test_deep_trees_blocks_and_runs_under_emulation():
+    cases = _mixed_cases()
+    out = emu_encode(cases)
+    for b, (r, payload) in zip(cases, out):
+        assert r.status == 1
+        check_roundtrip(b, r.method, payload)
+    assert out[0][0].method == 8 and out[2][0].method == 8
+
+
 def test_framings_that_only_add_bytes_end_as_store_under_emulation():
     b = corpus.gen_text(3, 1500)
     for m in (0, 93, 100, 97, 14):
@@ -74,6 +111,37 @@ def test_gpu_encode_roundtrip_and_ratio(gpu_lib):
 
 
 @pytest.mark.gpu
+def test_gpu_mixed_and_random_shapes(gpu_lib):
+    """Deep trees, multi-block buffers, runs, and 1 500 buffers of random kind and length."""
+    import random
+    r = random.Random(99)
+    cases = _mixed_cases()
+    for i in range(1500):
+        kind, n = r.randrange(5), r.choice([0, 1, 3, 4, 5, 63, 64, 65, 255, 256, 257, 1000, 4096, 20000, 65536, 70000]) + r.randrange(3)
+        if kind == 0:
+            cases.append(corpus.gen_text(1000 + i, n))
+        elif kind == 1:
+            cases.append(bytes(r.randrange(256) for _ in range(min(n, 5000))))
+        elif kind == 2:
+            cases.append(bytes(r.randrange(4) for _ in range(min(n, 20000))))
+        elif kind == 3:
+            cases.append((corpus.gen_text(i, 50) * (n // 50 + 1))[:n])
+        else:
+            cases.append(_skewed(max(n, 40), i, 12 + r.randrange(30)))
+    out = gpu_lib.encode_batch_host(cases, 8)
+    for b, (method, payload, crc) in zip(cases, out):
+        assert crc == zlib.crc32(b) & 0xFFFFFFFF
+        check_roundtrip(b, method, payload)
+    items, blob = [], bytearray()
+    for b, (method, payload, crc) in zip(cases, out):
+        items.append((method, len(blob), len(payload), len(b), crc))
+        blob += payload
+    dec = gpu_lib.decode_batch_host(bytes(blob) + b"\0" * 16, items)
+    for i, b in enumerate(cases):
+        assert dec.ok(i) and dec.data(i) == b, i
+
+
+@pytest.mark.gpu
 def test_gpu_config5_shape(gpu_lib):
     """configs[4] at reduced count: 500 x 64 KiB buffers, level-6 request, round trip exact,
     every ratio above the reference's (which is ~1.35 on this corpus)."""
@@ -83,7 +151,7 @@ def test_gpu_config5_shape(gpu_lib):
     for b, (method, payload, crc) in zip(bufs, out):
         assert method == 8 and zlib.decompress(payload, -15) == b and crc == zlib.crc32(b) & 0xFFFFFFFF
         total += len(payload)
-    assert 500 * 65536 / total > 1.5
+    assert 500 * 65536 / total >= 2.2                                  # zlib level 6 reaches 2.51 on this corpus
 
 
 def _private_cases():
