@@ -838,7 +838,7 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 			u32 nB = 0, bytesB = 0, tstartB = 0;
 #pragma unroll 1
 			for (u32 it = 0; it < 64u; it++) {
-				const u32 prev = otz_shfl_up (exit_cur, 1);
+				const u32 prev = otz_lane_up1 (exit_cur, exit_cur);
 				// the left neighbour's exit is slot-relative to ITS slot: one segment further left
 				const u32 nt = lane && OTZ_X_KIND (prev) == OTZ_X_NORMAL ? OTZ_X_POS (prev) - OTZ_K1_S : OTZ_K1_NONE;
 				const bool moved = lane != 0 && nt != t && nt != OTZ_K1_NONE;

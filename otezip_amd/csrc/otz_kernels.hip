@@ -204,7 +204,8 @@ __device__ __forceinline__ void otz_encode_grid(const u8 *src, u8 *dst, const oz
 			break;
 		}
 		ozg_enc_entry e = entries[i];
-		if (!otz_enc_entry_in_bounds (e, src_len, dst_len)) {
+		// (the verdict is the same in every lane; saying so keeps the loop's control flow uniform)
+		if (otz_uniform (otz_enc_entry_in_bounds (e, src_len, dst_len) ? 1u : 0u) == 0u) {
 			if (otz_tid () == 0) {
 				results[i].status = OZG_ST_INTERNAL;
 				results[i].comp_size = 0;
@@ -212,6 +213,7 @@ __device__ __forceinline__ void otz_encode_grid(const u8 *src, u8 *dst, const oz
 				results[i].method = e.method;
 				results[i].flags = 0;
 			}
+			otz_wave_sync ();
 			continue;
 		}
 		otz_encode_entry<PROF> (L, src, dst, e, &results[i], my_tok, PROF && prof ? prof + 32ull * i : nullptr);
