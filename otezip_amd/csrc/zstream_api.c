@@ -32,8 +32,8 @@
  *  - on an error return (Z_DATA_ERROR, Z_BUF_ERROR) nothing is consumed and nothing written;
  *  - inflate: parity rules of DESIGN.md apply (the reference's premature Z_BUF_ERROR on
  *    some valid streams is repaired; malformed input fails cleanly);
- *  - deflate: the level is ignored and the output is a VALID fixed-Huffman stream (the
- *    reference's is not); only sizes are comparable;
+ *  - deflate: the level is ignored and the output is VALID DEFLATE, dynamic-Huffman blocks (the
+ *    reference's is not valid); only sizes are comparable;
  *  - zstdCompress finishes in one call (the reference wants to be called until it stops
  *    returning Z_OK, ref otezip.c:878-881); the bytes are the same.
  * The container writers are byte-exact, including the reference encoder's own magic byte order

@@ -7,7 +7,7 @@ tag=${1:-rXX}
 out=gpurun_out/profile_${tag}
 mkdir -p $out
 echo "[profile] bench line"
-python3 bench.py --steps 20 --warmup 3 > $out/bench.json 2> $out/bench.err || tail -3 $out/bench.err
+timeout -k 10 400 python3 bench.py --steps 20 --warmup 3 > $out/bench.json 2> $out/bench.err || tail -3 $out/bench.err
 cut -c1-300 $out/bench.json
 echo "[profile] kernel trace of bench.py"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_bench -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $out/trace_bench.log 2>&1
@@ -27,7 +27,9 @@ for c in FETCH_SIZE WRITE_SIZE; do find $out/pmc_$c -name "*counter_collection.c
 echo "[profile] SQ counters"
 tools/sq_counters.sh ${tag} > $out/sq.log 2>&1; cp gpurun_out/sq_summary_${tag}.json $out/sq_summary.json 2>/dev/null; grep -c SQ_ $out/sq_summary.json
 echo "[profile] phases"
-python3 tools/prof_phases.py 4000 > $out/phases.txt 2>&1; grep -v "amdgpu.ids\|  0 cyc" $out/phases.txt
+timeout -k 10 200 python3 tools/prof_phases.py 4000 > $out/phases.txt 2>&1; grep -v "amdgpu.ids\|  0 cyc" $out/phases.txt
+echo "[profile] encoder: throughput, ratio, phases"
+timeout -k 10 200 python3 tools/prof_encode.py 10000 > $out/encode_phases.txt 2>&1; grep -v "amdgpu.ids" $out/encode_phases.txt
 echo "[profile] LDS access costs"
 tools/ubench/lds_unaligned > $out/lds_access_costs.txt 2>&1 || true
 rm -rf $out/trace_bench $out/trace_secondary $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE
