@@ -181,6 +181,11 @@ int ozg_encode_batch_device(const void *d_src, uint64_t src_len, void *d_dst, ui
 	const ozg_enc_entry *d_entries, ozg_enc_result *d_results, uint32_t n, void *stream);
 int ozg_encode_batch_host(const void *src, uint64_t src_len, void *dst, uint64_t dst_len,
 	const ozg_enc_entry *entries, ozg_enc_result *results, uint32_t n);
+/* The encode side of the asynchronous pipeline (ozg_job_wait / ozg_job_done as for decode; what
+ * zip_close's batched writer drives): one job = H2D of the sources, otezip_compress_data
+ * (ref src/lib/otezip.c:788-1076) + CRC-32 (:1124) for every buffer, D2H.  Pinned buffers. */
+int ozg_encode_submit(const void *h_src, uint64_t src_len, void *h_dst, uint64_t dst_len,
+	const ozg_enc_entry *entries, ozg_enc_result *h_results, uint32_t n, ozg_job **job);
 
 /* crc[i] = CRC-32 of d_buf[off[i] .. off[i]+len[i]) (all device pointers). */
 int ozg_crc32_batch_device(const void *d_buf, const uint64_t *d_off, const uint32_t *d_len, uint32_t *d_crc,

@@ -740,8 +740,8 @@ OTZ_DEV u32 otz_deflate_entry(otz_enc_lds &L, const u8 *src, u32 n, u8 *dst, u32
 				u64 sel = (u64)otz_readlane ((u32)R[u], skip) | (u64)otz_readlane ((u32) (R[u] >> 32), skip) << 32;
 				skip = otz_readlane (J[u], skip) - 64u;
 #endif
-				if (lim < 64u) {
-					sel &= (1ull << lim) - 1ull;
+				if (TAIL && lim < 64u) {
+					sel &= (1ull << (lim & 63u)) - 1ull;
 				}
 				if ((sel >> lane) & 1ull) {
 					u32 t;

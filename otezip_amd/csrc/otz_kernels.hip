@@ -758,6 +758,20 @@ int ozg_decode_batch_host_ex(const void *src, uint64_t src_len, void *dst, uint6
 
 // ---- asynchronous staged batches: the ingest / egress pipeline of the zip layer
 
+static int check_enc_entries(const ozg_enc_entry *entries, uint32_t n, uint64_t src_len, uint64_t dst_len) {
+	for (uint32_t i = 0; i < n; i++) {
+		const ozg_enc_entry &e = entries[i];
+		const bool codec_only = (e.reserved & OZG_ENC_F_CODEC_ONLY) != 0;
+		if (e.src_off > src_len || e.src_size > src_len - e.src_off || (e.dst_off & 15u) || e.dst_off > dst_len ||
+			e.dst_cap > dst_len - e.dst_off || (e.dst_cap < e.src_size && !codec_only)) {
+			snprintf (g_err, sizeof (g_err), "encode entry %u: offsets outside the buffers, dst_off not a multiple of 16, or dst_cap < src_size", i);
+			return OZG_E_ARG;
+		}
+	}
+	return OZG_OK;
+}
+
+
 int ozg_decode_submit(const void *h_src, uint64_t src_len, void *h_dst, uint64_t dst_len, const ozg_entry *entries,
 	ozg_result *h_results, uint32_t n, ozg_job **job) {
 	dev_ctx *C;
@@ -813,6 +827,67 @@ int ozg_decode_submit(const void *h_src, uint64_t src_len, void *h_dst, uint64_t
 	}
 	OZG_HIP (hipMemcpyAsync (h_dst, J->st.d_dst, dst_len, hipMemcpyDeviceToHost, s));
 	OZG_HIP (hipMemcpyAsync (h_results, J->st.d_res, (size_t)n * sizeof (ozg_result), hipMemcpyDeviceToHost, s));
+	OZG_HIP (hipEventRecord (J->done, s));
+	J->busy = true;
+	*job = J;
+	return OZG_OK;
+}
+
+// the encode side of the same pipeline: H2D, encode + CRC kernels, D2H on the job's stream
+int ozg_encode_submit(const void *h_src, uint64_t src_len, void *h_dst, uint64_t dst_len, const ozg_enc_entry *entries,
+	ozg_enc_result *h_results, uint32_t n, ozg_job **job) {
+	dev_ctx *C;
+	int rc = need_ctx (&C);
+	if (rc != OZG_OK) {
+		return rc;
+	}
+	if (!job || !h_src || !h_dst || !entries || !h_results || n == 0) {
+		snprintf (g_err, sizeof (g_err), "null pointer or empty batch");
+		return OZG_E_ARG;
+	}
+	if ((rc = check_enc_entries (entries, n, src_len, dst_len)) != OZG_OK) {
+		return rc;
+	}
+	std::lock_guard<std::mutex> lk (g_mu);
+	ozg_job *J = nullptr;
+	for (int k = 0; k < N_SLOTS; k++) {
+		if (!C->slots[k].busy) {
+			J = &C->slots[k];
+			break;
+		}
+	}
+	if (!J) {
+		snprintf (g_err, sizeof (g_err), "all %d staged-batch slots of the device are in flight", N_SLOTS);
+		return OZG_E_NOMEM;
+	}
+	if (!J->stream) {
+		OZG_HIP (hipStreamCreateWithFlags (&J->stream, hipStreamNonBlocking));
+		OZG_HIP (hipEventCreateWithFlags (&J->done, hipEventDisableTiming));
+	}
+	J->dev = g_cur;
+	const size_t ent_bytes = (size_t)n * sizeof (ozg_enc_entry);
+	if ((rc = staging_reserve (J->st, src_len + 64, dst_len + 64, ent_bytes, (size_t)n * sizeof (ozg_enc_result))) != OZG_OK) {
+		return rc;
+	}
+	if (ent_bytes > J->h_ent_cap) {
+		if (J->h_ent) {
+			(void)hipHostFree (J->h_ent);
+			J->h_ent = nullptr;
+			J->h_ent_cap = 0;
+		}
+		OZG_HIP (hipHostMalloc (&J->h_ent, ent_bytes + (ent_bytes >> 1), hipHostMallocDefault));
+		J->h_ent_cap = ent_bytes + (ent_bytes >> 1);
+	}
+	memcpy (J->h_ent, entries, ent_bytes);
+	hipStream_t s = J->stream;
+	OZG_HIP (hipMemcpyAsync (J->st.d_src, h_src, src_len, hipMemcpyHostToDevice, s));
+	OZG_HIP (hipMemcpyAsync (J->st.d_ent, J->h_ent, ent_bytes, hipMemcpyHostToDevice, s));
+	rc = ozg_encode_batch_device (J->st.d_src, src_len, J->st.d_dst, dst_len, (const ozg_enc_entry *)J->st.d_ent, (ozg_enc_result *)J->st.d_res, n, s);
+	if (rc != OZG_OK) {
+		return rc;
+	}
+	OZG_HIP (hipMemcpyAsync (h_dst, J->st.d_dst, dst_len, hipMemcpyDeviceToHost, s));
+	OZG_HIP (hipMemcpyAsync (h_results, J->st.d_res, (size_t)n * sizeof (ozg_enc_result), hipMemcpyDeviceToHost, s));
 	OZG_HIP (hipEventRecord (J->done, s));
 	J->busy = true;
 	*job = J;
@@ -922,14 +997,8 @@ int ozg_encode_batch_host(const void *src, uint64_t src_len, void *dst, uint64_t
 		snprintf (g_err, sizeof (g_err), "null pointer");
 		return OZG_E_ARG;
 	}
-	for (uint32_t i = 0; i < n; i++) {
-		const ozg_enc_entry &e = entries[i];
-		const bool codec_only = (e.reserved & OZG_ENC_F_CODEC_ONLY) != 0;
-		if (e.src_off > src_len || e.src_size > src_len - e.src_off || (e.dst_off & 15u) || e.dst_off > dst_len ||
-			e.dst_cap > dst_len - e.dst_off || (e.dst_cap < e.src_size && !codec_only)) {
-			snprintf (g_err, sizeof (g_err), "encode entry %u: offsets outside the buffers, dst_off not a multiple of 16, or dst_cap < src_size", i);
-			return OZG_E_ARG;
-		}
+	if ((rc = check_enc_entries (entries, n, src_len, dst_len)) != OZG_OK) {
+		return rc;
 	}
 	std::lock_guard<std::mutex> lk (g_mu);
 	staging &S = C->stage;

@@ -52,6 +52,8 @@
  * zip_set_file_compression reaches every entry added since. */
 #define PEND_FLUSH_BYTES (3ull << 30)
 #define PEND_FLUSH_ITEMS 65535u
+#define PCHUNK_BYTES ((size_t)32 << 20) /* sources per encode batch (an entry larger than this gets a chunk of its own) */
+#define PCHUNK_ITEMS 16384u
 
 int otezip_verify_crc = 0;
 uint64_t otezip_max_expansion_ratio = 1000ULL;
@@ -81,8 +83,16 @@ struct window {
 
 struct pend_item {
 	zip_uint64_t index;
-	uint64_t off;
+	uint64_t off; /* inside its chunk */
 	uint32_t len;
+};
+
+/* sources of added entries wait in plain heap chunks (pinning memory costs more than copying it
+ * once more into a pinned buffer that is reused); a chunk is one encode batch */
+struct pchunk {
+	uint8_t *buf;
+	size_t cap, used;
+	size_t item0, nitems; /* its entries: pit[item0 .. item0 + nitems) */
 };
 
 struct ozh_zip {
@@ -94,8 +104,9 @@ struct ozh_zip {
 	uint32_t cd_ofs;       /* start of the central directory when the archive was opened */
 	int ndev, next_dev;
 	/* deferred zip_file_add: sources, in index order */
-	uint8_t *pbuf;
-	size_t pcap, pused;
+	struct pchunk *pch;
+	size_t npch, pchcap;
+	size_t ptotal; /* bytes pending in all chunks */
 	struct pend_item *pit;
 	size_t pn, pncap;
 	int write_failed;
@@ -131,7 +142,9 @@ static int g_ndev = 1, g_dev0 = 0;
 
 /* OTEZIP_GPU_DEVICE = first device (default 0), OTEZIP_GPU_DEVICES = how many consecutive
  * devices the windows of an archive are dealt to (default 1) */
+static pthread_mutex_t g_gpu_mu = PTHREAD_MUTEX_INITIALIZER;
 static int gpu_up(void) {
+	pthread_mutex_lock (&g_gpu_mu);
 	if (g_gpu_state == 0) {
 		TRACE ("initialising the GPU");
 		const char *dev = getenv ("OTEZIP_GPU_DEVICE"), *cnt = getenv ("OTEZIP_GPU_DEVICES");
@@ -150,6 +163,7 @@ static int gpu_up(void) {
 				fprintf (stderr, "otezip-amd: %s\n", ozg_last_error ());
 				if (k == 0) {
 					g_gpu_state = -1;
+					pthread_mutex_unlock (&g_gpu_mu);
 					return 0;
 				}
 				want = k;
@@ -160,7 +174,28 @@ static int gpu_up(void) {
 		g_gpu_state = 1;
 		TRACE ("devices ready: %d from %d", g_ndev, g_dev0);
 	}
-	return g_gpu_state == 1;
+	const int up = g_gpu_state == 1;
+	pthread_mutex_unlock (&g_gpu_mu);
+	return up;
+}
+
+/* Creating the HIP context takes a quarter of a second: a writer starts it in the background at
+ * its first zip_file_add, so that it overlaps with the adds (whoever needs the GPU first waits
+ * on the mutex inside gpu_up). */
+static void *gpu_up_thread(void *arg) {
+	(void)arg;
+	(void)gpu_up ();
+	return NULL;
+}
+static void gpu_up_in_background(void) {
+	static int started;
+	if (g_gpu_state != 0 || __atomic_exchange_n (&started, 1, __ATOMIC_ACQ_REL)) {
+		return;
+	}
+	pthread_t t;
+	if (pthread_create (&t, NULL, gpu_up_thread, NULL) == 0) {
+		pthread_detach (t);
+	}
 }
 
 /* ------------------------------------------------------------ small helpers */
@@ -439,19 +474,16 @@ static void winbuf_free(struct winbuf *b) {
 static struct winbuf g_pool[POOL_SETS];
 static pthread_mutex_t g_pool_mu = PTHREAD_MUTEX_INITIALIZER;
 
-static void window_free(struct window *w) {
-	if (!w) {
+/* give a pinned set back: kept for the next user if there is room, or if it is larger than a kept one */
+static void winbuf_put(struct winbuf *b) {
+	if (!b->src && !b->out && !b->res) {
 		return;
-	}
-	if (w->job) {
-		ozg_job_wait (w->job); /* the copies still write into its buffers */
-		w->job = NULL;
 	}
 	int kept = 0;
 	pthread_mutex_lock (&g_pool_mu);
 	for (int i = 0; i < POOL_SETS; i++) {
 		if (!g_pool[i].src && !g_pool[i].out && !g_pool[i].res) {
-			g_pool[i] = w->b;
+			g_pool[i] = *b;
 			kept = 1;
 			break;
 		}
@@ -463,16 +495,29 @@ static void window_free(struct window *w) {
 				small = i;
 			}
 		}
-		if (g_pool[small].out_cap < w->b.out_cap) {
+		if (g_pool[small].out_cap < b->out_cap) {
 			struct winbuf t = g_pool[small];
-			g_pool[small] = w->b;
-			w->b = t;
+			g_pool[small] = *b;
+			*b = t;
 		}
 	}
 	pthread_mutex_unlock (&g_pool_mu);
 	if (!kept) {
-		winbuf_free (&w->b);
+		winbuf_free (b);
+	} else {
+		memset (b, 0, sizeof (*b));
 	}
+}
+
+static void window_free(struct window *w) {
+	if (!w) {
+		return;
+	}
+	if (w->job) {
+		ozg_job_wait (w->job); /* the copies still write into its buffers */
+		w->job = NULL;
+	}
+	winbuf_put (&w->b);
 	free (w->off);
 	free (w->res);
 	free (w->valid);
@@ -653,6 +698,7 @@ static int finalize(zip_t *za) {
 }
 
 static int flush_pending(zip_t *za);
+static void pending_drop(struct ozh_zip *z);
 
 int zip_close(zip_t *za) {
 	/* ref otezip.c:1273-1295 */
@@ -685,7 +731,8 @@ int zip_close(zip_t *za) {
 	}
 	window_detach (z->win);
 	window_detach (z->ahead);
-	ozg_free_pinned (z->pbuf);
+	pending_drop (z);
+	free (z->pch);
 	free (z->pit);
 	free (z);
 	return rc;
@@ -1117,45 +1164,117 @@ void zip_source_free(zip_source_t *src) {
  * input; local headers and payloads are then written in index order.  Methods 93/100/97
  * always end as STORE, exactly as in the reference, whose writers for them only add bytes
  * (SURVEY F9). */
-static int flush_pending(zip_t *za) {
-	struct ozh_zip *z = (struct ozh_zip *)za;
-	const size_t n = z->pn;
-	if (n == 0) {
-		return 0;
+static void pending_drop(struct ozh_zip *z) {
+	for (size_t k = 0; k < z->npch; k++) {
+		free (z->pch[k].buf);
 	}
-	if (!gpu_up ()) {
-		z->write_failed = 1;
+	z->npch = 0;
+	z->pn = 0;
+	z->ptotal = 0;
+}
+
+/* one chunk's batch on its way through the GPU */
+struct enc_flight {
+	struct winbuf b;
+	ozg_enc_entry *ee;
+	ozg_job *job;
+	size_t chunk;
+	int live;
+};
+
+/* copy chunk k into pinned memory and submit its encode */
+static int enc_start(zip_t *za, size_t k, struct enc_flight *f) {
+	struct ozh_zip *z = (struct ozh_zip *)za;
+	const struct pchunk *c = &z->pch[k];
+	memset (f, 0, sizeof (*f));
+	f->chunk = k;
+	f->ee = (ozg_enc_entry *)calloc (c->nitems ? c->nitems : 1, sizeof (*f->ee));
+	if (!f->ee) {
 		return -1;
 	}
-	int rc = -1;
-	ozg_enc_entry *ee = (ozg_enc_entry *)calloc (n, sizeof (*ee));
-	ozg_enc_result *er = NULL;
-	uint8_t *out = NULL;
 	uint64_t ocap = 0;
-	if (!ee) {
-		goto done;
-	}
-	for (size_t i = 0; i < n; i++) {
-		const struct otezip_entry *e = &za->entries[z->pit[i].index];
-		ee[i].src_off = z->pit[i].off;
-		ee[i].src_size = z->pit[i].len;
-		ee[i].method = e->method; /* (what zip_set_file_compression left there) */
-		ee[i].dst_off = ocap;
-		const uint64_t cap = ozg_compress_bound (e->method, z->pit[i].len);
-		ee[i].dst_cap = (uint32_t)cap;
+	for (size_t i = 0; i < c->nitems; i++) {
+		const struct pend_item *it = &z->pit[c->item0 + i];
+		const struct otezip_entry *e = &za->entries[it->index];
+		f->ee[i].src_off = it->off;
+		f->ee[i].src_size = it->len;
+		f->ee[i].method = e->method; /* (what zip_set_file_compression left there) */
+		f->ee[i].dst_off = ocap;
+		const uint64_t cap = ozg_compress_bound (e->method, it->len);
+		f->ee[i].dst_cap = (uint32_t)cap;
 		ocap += (cap + 15u) & ~15ull;
 	}
-	ozg_use_device (g_dev0);
-	out = (uint8_t *)ozg_malloc_pinned ((size_t)ocap + 64);
-	er = (ozg_enc_result *)ozg_malloc_pinned (n * sizeof (*er));
-	if (!out || !er) {
+	if (winbuf_get (z, &f->b, c->used + 64, (size_t)ocap + 64, c->nitems) != 0) {
 		fprintf (stderr, "otezip-amd: %s\n", ozg_last_error ());
-		goto done;
+		free (f->ee);
+		f->ee = NULL;
+		return -1;
 	}
-	if (ozg_encode_batch_host (z->pbuf, z->pused + 16, out, ocap + 16, ee, er, (uint32_t)n) != OZG_OK) {
+	memcpy (f->b.src, c->buf, c->used);
+	if (ozg_encode_submit (f->b.src, c->used + 16, f->b.out, ocap + 16, f->ee, (ozg_enc_result *)f->b.res, (uint32_t)c->nitems, &f->job) != OZG_OK) {
+		fprintf (stderr, "otezip-amd: GPU encode failed: %s\n", ozg_last_error ());
+		winbuf_put (&f->b);
+		free (f->ee);
+		f->ee = NULL;
+		return -1;
+	}
+	f->live = 1;
+	TRACE ("encode batch %zu: %zu entries, %zu bytes submitted", k, c->nitems, c->used);
+	return 0;
+}
+
+/* wait for a chunk's batch and append its local headers + payloads to the file */
+static int enc_finish(zip_t *za, struct enc_flight *f, uint64_t *at) {
+	struct ozh_zip *z = (struct ozh_zip *)za;
+	int rc = -1;
+	if (!f->live) {
+		return -1;
+	}
+	const struct pchunk *c = &z->pch[f->chunk];
+	const ozg_enc_result *er = (const ozg_enc_result *)f->b.res;
+	if (ozg_job_wait (f->job) != OZG_OK) {
 		fprintf (stderr, "otezip-amd: GPU encode failed: %s\n", ozg_last_error ());
 		goto done;
 	}
+	for (size_t i = 0; i < c->nitems; i++) {
+		struct otezip_entry *e = &za->entries[z->pit[c->item0 + i].index];
+		if (er[i].status != OZG_ST_OK || *at > UINT32_MAX) {
+			goto done;
+		}
+		e->method = er[i].method;
+		e->crc32 = er[i].crc32;
+		e->comp_size = er[i].comp_size;
+		e->local_hdr_ofs = (uint32_t)*at;
+		*at += write_lfh (za->fp, e);
+		if (er[i].comp_size && fwrite (f->b.out + f->ee[i].dst_off, 1, er[i].comp_size, za->fp) != er[i].comp_size) {
+			goto done;
+		}
+		*at += er[i].comp_size;
+	}
+	rc = 0;
+	TRACE ("encode batch %zu written", f->chunk);
+done:
+	winbuf_put (&f->b);
+	free (f->ee);
+	f->ee = NULL;
+	f->live = 0;
+	return rc;
+}
+
+/* Encode everything that is pending and write it: chunk k + 1 is on the GPU while chunk k's
+ * output goes to the file. */
+static int flush_pending(zip_t *za) {
+	struct ozh_zip *z = (struct ozh_zip *)za;
+	if (z->pn == 0) {
+		return 0;
+	}
+	int rc = -1;
+	struct enc_flight fl[2];
+	memset (fl, 0, sizeof (fl));
+	if (!gpu_up ()) {
+		goto done;
+	}
+	ozg_use_device (g_dev0);
 	if (fseek (za->fp, 0, SEEK_END) != 0) {
 		goto done;
 	}
@@ -1164,63 +1283,69 @@ static int flush_pending(zip_t *za) {
 		goto done;
 	}
 	uint64_t at = (uint64_t)pos;
-	for (size_t i = 0; i < n; i++) {
-		struct otezip_entry *e = &za->entries[z->pit[i].index];
-		if (er[i].status != OZG_ST_OK || at > UINT32_MAX) {
+	for (size_t k = 0; k <= z->npch; k++) {
+		if (k < z->npch && enc_start (za, k, &fl[k & 1u]) != 0) {
 			goto done;
 		}
-		e->method = er[i].method;
-		e->crc32 = er[i].crc32;
-		e->comp_size = er[i].comp_size;
-		e->local_hdr_ofs = (uint32_t)at;
-		at += write_lfh (za->fp, e);
-		if (er[i].comp_size && fwrite (out + ee[i].dst_off, 1, er[i].comp_size, za->fp) != er[i].comp_size) {
+		if (k > 0 && enc_finish (za, &fl[(k - 1u) & 1u], &at) != 0) {
 			goto done;
 		}
-		at += er[i].comp_size;
 	}
 	rc = 0;
 done:
-	ozg_free_pinned (out);
-	ozg_free_pinned (er);
-	free (ee);
-	z->pn = 0;
-	z->pused = 0;
+	for (int k = 0; k < 2; k++) {
+		if (fl[k].live) {
+			(void)ozg_job_wait (fl[k].job);
+			winbuf_put (&fl[k].b);
+			free (fl[k].ee);
+		}
+	}
+	pending_drop (z);
 	if (rc != 0) {
 		z->write_failed = 1;
 	}
 	return rc;
 }
 
-/* room for len more source bytes in the pinned batch buffer */
-static int pending_reserve(struct ozh_zip *z, size_t len) {
-	const size_t need = z->pused + ((len + 15u) & ~(size_t)15u) + 64;
-	if (need > z->pcap) {
-		size_t cap = z->pcap ? z->pcap : (size_t)4 << 20;
-		while (cap < need) {
-			cap *= 2;
-		}
-		uint8_t *nb = (uint8_t *)ozg_malloc_pinned (cap);
-		if (!nb) {
-			return -1;
-		}
-		if (z->pused) {
-			memcpy (nb, z->pbuf, z->pused);
-		}
-		ozg_free_pinned (z->pbuf);
-		z->pbuf = nb;
-		z->pcap = cap;
-	}
+/* room for len more source bytes and one more item; returns where the bytes go */
+static uint8_t *pending_reserve(struct ozh_zip *z, size_t len, uint64_t *off) {
+	const size_t alen = (len + 15u) & ~(size_t)15u;
 	if (z->pn == z->pncap) {
 		size_t nc = z->pncap ? 2 * z->pncap : 1024;
 		struct pend_item *ni = (struct pend_item *)realloc (z->pit, nc * sizeof (*ni));
 		if (!ni) {
-			return -1;
+			return NULL;
 		}
 		z->pit = ni;
 		z->pncap = nc;
 	}
-	return 0;
+	struct pchunk *c = z->npch ? &z->pch[z->npch - 1] : NULL;
+	if (!c || c->used + alen + 64 > c->cap || c->nitems >= PCHUNK_ITEMS) {
+		if (z->npch == z->pchcap) {
+			size_t nc = z->pchcap ? 2 * z->pchcap : 16;
+			struct pchunk *np = (struct pchunk *)realloc (z->pch, nc * sizeof (*np));
+			if (!np) {
+				return NULL;
+			}
+			z->pch = np;
+			z->pchcap = nc;
+		}
+		c = &z->pch[z->npch];
+		memset (c, 0, sizeof (*c));
+		c->cap = alen + 64 > PCHUNK_BYTES ? alen + 64 : PCHUNK_BYTES;
+		c->buf = (uint8_t *)malloc (c->cap);
+		if (!c->buf) {
+			return NULL;
+		}
+		c->item0 = z->pn;
+		z->npch++;
+	}
+	*off = c->used;
+	uint8_t *at = c->buf + c->used;
+	c->used += alen;
+	c->nitems++;
+	z->ptotal += alen;
+	return at;
 }
 
 zip_int64_t zip_file_add(zip_t *za, const char *name, zip_source_t *src, zip_flags_t flags) {
@@ -1234,10 +1359,11 @@ zip_int64_t zip_file_add(zip_t *za, const char *name, zip_source_t *src, zip_fla
 	if (nl > MAX_FIELD_LEN || src->len > MAX_PAYLOAD || src->len > UINT32_MAX) {
 		return -1;
 	}
-	if (!gpu_up ()) {
+	if (g_gpu_state < 0) {
 		return -1; /* there is no CPU encoder to fall back to */
 	}
-	if (z->pn >= PEND_FLUSH_ITEMS || (z->pn && z->pused + src->len > PEND_FLUSH_BYTES)) {
+	gpu_up_in_background ();
+	if (z->pn >= PEND_FLUSH_ITEMS || (z->pn && z->ptotal + src->len > PEND_FLUSH_BYTES)) {
 		if (flush_pending (za) != 0) {
 			return -1;
 		}
@@ -1249,7 +1375,9 @@ zip_int64_t zip_file_add(zip_t *za, const char *name, zip_source_t *src, zip_fla
 	za->entries = ne;
 	struct otezip_entry *e = &za->entries[za->n_entries];
 	memset (e, 0, sizeof (*e));
-	if (pending_reserve (z, (size_t)src->len) != 0) {
+	uint64_t poff = 0;
+	uint8_t *pat = pending_reserve (z, (size_t)src->len, &poff);
+	if (!pat) {
 		return -1; /* src stays with the caller, as in the reference */
 	}
 	e->name = (char *)malloc (nl + 1);
@@ -1265,12 +1393,11 @@ zip_int64_t zip_file_add(zip_t *za, const char *name, zip_source_t *src, zip_fla
 	 * when it returns (comp_size, CRC and offset follow when the batch is encoded) */
 	struct pend_item *it = &z->pit[z->pn++];
 	it->index = za->n_entries;
-	it->off = z->pused;
+	it->off = poff;
 	it->len = (uint32_t)src->len;
 	if (src->len) {
-		memcpy (z->pbuf + z->pused, src->buf, (size_t)src->len);
+		memcpy (pat, src->buf, (size_t)src->len);
 	}
-	z->pused += ((size_t)src->len + 15u) & ~(size_t)15u;
 	if (src->freep) {
 		free ((void *)src->buf);
 	}
@@ -1291,7 +1418,9 @@ int zip_file_replace(zip_t *za, zip_uint64_t index, zip_source_t *src, zip_flags
 		return -1;
 	}
 	/* the entry's new bytes: a batch of one, written at once */
-	if (pending_reserve (z, (size_t)src->len) != 0) {
+	uint64_t poff = 0;
+	uint8_t *pat = pending_reserve (z, (size_t)src->len, &poff);
+	if (!pat) {
 		return -1;
 	}
 	struct otezip_entry *e = &za->entries[index];
@@ -1299,12 +1428,11 @@ int zip_file_replace(zip_t *za, zip_uint64_t index, zip_source_t *src, zip_flags
 	e->uncomp_size = (uint32_t)src->len; /* (the entry keeps its method, ref :1630) */
 	struct pend_item *it = &z->pit[z->pn++];
 	it->index = index;
-	it->off = 0;
+	it->off = poff;
 	it->len = (uint32_t)src->len;
 	if (src->len) {
-		memcpy (z->pbuf, src->buf, (size_t)src->len);
+		memcpy (pat, src->buf, (size_t)src->len);
 	}
-	z->pused = ((size_t)src->len + 15u) & ~(size_t)15u;
 	if (flush_pending (za) != 0) {
 		char *nm = e->name;
 		*e = keep;
