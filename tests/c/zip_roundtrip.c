@@ -12,6 +12,8 @@
  *   zip_roundtrip bench-add PATH INPUT N SIZE
  *                                         -> adds N buffers of SIZE bytes read from INPUT with default method STORE,
  *                                            sets DEFLATE on every one, closes; prints "TOTAL bytes seconds"
+ *   zip_roundtrip add-list PATH INPUT SIZES [STAT_EVERY]
+ *                                         -> ragged adds (sizes from the text file SIZES), DEFLATE set on each
  *   zip_roundtrip replace PATH            -> append + zip_file_replace + read-back scenario; exit 0 on success
  */
 #define _POSIX_C_SOURCE 200809L
@@ -250,6 +252,48 @@ static int do_bench_add(const char *path, const char *input, unsigned n, unsigne
 	return 0;
 }
 
+/* ragged adds: SIZES holds one decimal size per line; the buffers follow one another in INPUT.  Every
+ * stat_every-th add is followed by a zip_stat_index of the new entry (which forces the pending batch out). */
+static int do_add_list(const char *path, const char *input, const char *sizes, unsigned stat_every) {
+	FILE *in = fopen (input, "rb"), *sf = fopen (sizes, "r");
+	if (!in || !sf) {
+		return 70;
+	}
+	int err = -1;
+	zip_t *za = zip_open (path, ZIP_CREATE | ZIP_TRUNCATE, &err);
+	if (!za) {
+		return 71;
+	}
+	za->default_method = ZIP_CM_STORE;
+	unsigned long sz;
+	unsigned i = 0;
+	while (fscanf (sf, "%lu", &sz) == 1) {
+		uint8_t *buf = (uint8_t *)malloc (sz ? sz : 1);
+		if (!buf || fread (buf, 1, sz, in) != sz) {
+			return 72;
+		}
+		char name[64];
+		snprintf (name, sizeof (name), "e%06u", i);
+		zip_source_t *src = zip_source_buffer (za, buf, sz, 1); /* freep: the library owns buf */
+		if (zip_file_add (za, name, src, 0) != (zip_int64_t)i) {
+			return 73;
+		}
+		if (zip_set_file_compression (za, i, ZIP_CM_DEFLATE, 0) != 0) {
+			return 74;
+		}
+		if (stat_every && (i + 1) % stat_every == 0) {
+			zip_stat_t st;
+			if (zip_stat_index (za, i, 0, &st) != 0 || st.size != sz) {
+				return 75;
+			}
+		}
+		i++;
+	}
+	fclose (in);
+	fclose (sf);
+	return zip_close (za) == 0 ? 0 : 76;
+}
+
 /* append mode, zip_file_replace and reading an entry back in the same session */
 static int do_replace(const char *path) {
 	int err = -1;
@@ -348,6 +392,9 @@ int main(int argc, char **argv) {
 	}
 	if (argc >= 6 && !strcmp (argv[1], "bench-add")) {
 		return do_bench_add (argv[2], argv[3], (unsigned)atoi (argv[4]), (unsigned)atoi (argv[5]));
+	}
+	if (argc >= 5 && !strcmp (argv[1], "add-list")) {
+		return do_add_list (argv[2], argv[3], argv[4], argc >= 6 ? (unsigned)atoi (argv[5]) : 0);
 	}
 	if (argc >= 3 && !strcmp (argv[1], "replace")) {
 		return do_replace (argv[2]);

@@ -269,6 +269,39 @@ def test_bulk_add_with_set_file_compression_full_count(prog, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("stat_every", [0, 700])
+def test_ragged_adds_cross_encode_batches(prog, tmp_path, stat_every):
+    """The writer encodes its pending sources in batches of 32 MiB / 16 384 entries: 40 000 tiny entries,
+    an entry larger than a batch, entries that end exactly on a batch boundary, and (second run) stats in
+    between that force partial flushes.  Python's zipfile must read everything back."""
+    import random
+    from otezip_amd import corpus
+    r = random.Random(4)
+    sizes = [r.choice([0, 1, 5, 60, 700]) for _ in range(40000)] + [40 << 20, 3, (32 << 20) - 64, 64, 1 << 20, 0, 65536]
+    blob = corpus.gen_text(77, 4 << 20)
+    inp = tmp_path / "in.bin"
+    off, bufs = 0, []
+    with open(inp, "wb") as f:
+        for sz in sizes:
+            b = (blob[off % 1000:] + blob * (sz // len(blob) + 1))[:sz]
+            off += 37
+            bufs.append(b)
+            f.write(b)
+    sz_file = tmp_path / "sizes.txt"
+    sz_file.write_text("\n".join(map(str, sizes)) + "\n")
+    p = str(tmp_path / "r.zip")
+    rc, out, err = run(prog, "add-list", p, str(inp), str(sz_file), str(stat_every))
+    assert rc == 0, (rc, err)
+    with zipfile.ZipFile(p) as z:
+        infos = z.infolist()
+        assert len(infos) == len(sizes)
+        for i in list(range(0, 40000, 997)) + list(range(40000, len(sizes))):
+            assert infos[i].file_size == sizes[i]
+            assert z.read(infos[i]) == bufs[i], i
+        assert infos[40000].compress_type == zipfile.ZIP_DEFLATED and infos[40000].compress_size < sizes[40000] // 2
+
+
+@pytest.mark.gpu
 def test_config3_full_count_mixed_archive_through_zip_open(prog, tmp_path):
     """BASELINE configs[3]: a 50 000-entry archive alternating the private lzfse (100) and BROT (97) framings,
     64 KiB payloads (3.3 GB), read through zip_open / zip_fopen_index: ~50 pipelined windows.  Every 211th
