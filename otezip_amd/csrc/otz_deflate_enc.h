@@ -13,22 +13,27 @@
 //
 // Per buffer, per block of OTZ_ENC_BLOCK input bytes, two passes:
 //
-//   PARSE  64 input positions per step, one per lane.  Every lane hashes the four bytes
-//          at its position, reads its bucket (the two most recent earlier positions with
-//          that hash), publishes its own position, and measures both candidates eight
-//          bytes at a time (dword-aligned LDS reads + v_alignbyte; see the access-cost
-//          table in otz_simt.h).  Matches are at least four bytes long (with a dynamic
-//          code three-byte matches cost more than their literals on text).  One step of
-//          lazy evaluation: a position whose right neighbour has a longer match becomes a
-//          literal.  The token chain through the 64 positions -- the only serial part of
-//          LZ77 parsing -- is found by POINTER DOUBLING: every lane knows where the chain
-//          goes from its own position (position + advance), six rounds of ds_bpermute
-//          give every lane the set of positions the chain visits from it and where it
-//          leaves the step; the lane the previous step ended on holds the answer.  Chosen
-//          lanes append their token to the block's token list (global scratch, 4 bytes
-//          per token) and count their symbols in LDS histograms.
+//   PARSE  256 input positions per iteration: OTZ_ENC_U = 4 independent steps of 64 positions
+//          (one per lane) are in flight together, because one step is a chain of dependent
+//          LDS round trips and LDS capacity allows only two wavefronts per SIMD.  Every lane
+//          hashes the four bytes at its position, reads its bucket (the most recent earlier
+//          position with that hash; two with OTZ_ENC_WAYS = 2), publishes its own position,
+//          and measures the candidate eight bytes at a time (dword-aligned LDS reads +
+//          v_alignbyte; see the access-cost table in otz_simt.h).  Candidate bytes are read
+//          unconditionally -- any address is inside the ring -- and compared without
+//          branches, so that all reads of an iteration are in flight at once.  Matches are
+//          at least four bytes long (with a dynamic code three-byte matches cost more than
+//          their literals on text).  One step of lazy evaluation: a position whose right
+//          neighbour has a longer match becomes a literal.  The token chain through the 64
+//          positions of a step -- the only serial part of LZ77 parsing -- is found by
+//          POINTER DOUBLING: every lane knows where the chain goes from its own position
+//          (position + advance), six rounds of ds_bpermute give every lane the set of
+//          positions the chain visits from it and where it leaves the step; the lane the
+//          previous step ended on holds the answer.  Chosen lanes append their token to
+//          the block's token list (global scratch, 4 bytes per token: symbols and extra
+//          bits) and count their symbols in LDS histograms.
 //   CODE   Huffman codes for the block from the histograms: symbols ranked by weight (all
-//          lanes), the two-queue merge (one lane, 285 steps), leaf depths by walking up
+//          lanes), the two-queue merge (one lane, one step per symbol in use), leaf depths by walking up
 //          (all lanes), depth limit 15 by the usual "move a leaf down" repair on the
 //          length counts, lengths re-dealt in rank order, canonical codes from ballots.
 //          The code lengths are run-length coded (symbols 16/17/18) and get their own
@@ -38,9 +43,9 @@
 //          prefix sum gives its bit offset, the tokens are OR-ed into a 1 KiB LDS bit
 //          buffer that is drained with coalesced 16-byte stores.
 //
-// LDS: 8 KiB input ring (matches reach 7 278 bytes back), 2048 two-way buckets (the code
-// construction borrows their place between the parse and the emit of a block), the bit
-// buffer, histograms and code tables: 19.5 KB per wavefront, eight buffers in flight per CU.
+// LDS: 8 KiB input ring (matches reach 7 150 bytes back), 4096 buckets (the code construction
+// borrows their place between the parse and the emit of a block), the bit buffer, histograms
+// and code tables: 19.5 KB per wavefront, eight buffers in flight per CU.
 #pragma once
 
 #include "otz_simt.h"
@@ -66,9 +71,6 @@
 #endif
 #define OTZ_ENC_HASH (1u << OTZ_ENC_HBITS)
 #define OTZ_ENC_HEAD_WORDS (OTZ_ENC_HASH * OTZ_ENC_WAYS / 2u)
-#ifndef OTZ_ENC_WALK
-#define OTZ_ENC_WALK 0                    // 1: pick the token chain by a scalar walk instead of pointer doubling
-#endif
 #define OTZ_ENC_OUT 1024u                 // bit buffer: drained by halves, a step adds at most 64 * 48 bits
 #define OTZ_ENC_BLOCK 65536u              // input bytes per DEFLATE block
 #define OTZ_ENC_MINLEN 4u
@@ -104,11 +106,7 @@ struct otz_enc_build {
 
 struct otz_enc_lds {
 	u32 win_w[OTZ_ENC_WIN / 4 + 4]; // the ring; its first 16 bytes are repeated behind its end, so that no read wraps
-#ifdef OTZ_ENC_DEBUG_NOALIAS
-	struct {
-#else
 	union {
-#endif
 		u32 head[OTZ_ENC_HEAD_WORDS]; // two ways: a word per bucket, [15:0] the most recent position with this hash
 		                              // (mod 64 Ki), [31:16] the one before; one way: a u16 per bucket
 		otz_enc_build b;
@@ -690,7 +688,6 @@ OTZ_DEV u32 otz_deflate_entry(otz_enc_lds &L, const u8 *src, u32 n, u8 *dst, u32
 				J[u] = lane + (take[u] ? len[u] : 1u);
 				R[u] = 1ull << lane;
 			}
-#if !OTZ_ENC_WALK
 			// J is kept premultiplied by four (ds_bpermute takes byte addresses).  A lane whose chain
 			// has left the step reads ITSELF from then on, which changes nothing: no selects.
 			// (the first round needs no mask from the other lane: one hop reaches J itself)
@@ -716,7 +713,6 @@ OTZ_DEV u32 otz_deflate_entry(otz_enc_lds &L, const u8 *src, u32 n, u8 *dst, u32
 			for (u32 u = 0; u < OTZ_ENC_U; u++) {
 				J[u] >>= 2;
 			}
-#endif
 			OTZ_ENC_MARK (2);
 #pragma unroll
 			for (u32 u = 0; u < OTZ_ENC_U; u++) {
@@ -728,18 +724,8 @@ OTZ_DEV u32 otz_deflate_entry(otz_enc_lds &L, const u8 *src, u32 n, u8 *dst, u32
 					break;
 				}
 				const u32 left = n - (p + 64u * u), lim = TAIL && left < 64u ? left : 64u;
-#if OTZ_ENC_WALK
-				u64 sel = 0;
-				u32 cur = skip;
-				while (cur < 64u) {
-					sel |= 1ull << cur;
-					cur = otz_readlane (J[u], cur);
-				}
-				skip = cur - 64u;
-#else
 				u64 sel = (u64)otz_readlane ((u32)R[u], skip) | (u64)otz_readlane ((u32) (R[u] >> 32), skip) << 32;
 				skip = otz_readlane (J[u], skip) - 64u;
-#endif
 				if (TAIL && lim < 64u) {
 					sel &= (1ull << (lim & 63u)) - 1ull;
 				}
