@@ -1211,7 +1211,8 @@ static int enc_start(zip_t *za, size_t k, struct enc_flight *f) {
 		return -1;
 	}
 	memcpy (f->b.src, c->buf, c->used);
-	if (ozg_encode_submit (f->b.src, c->used + 16, f->b.out, ocap + 16, f->ee, (ozg_enc_result *)f->b.res, (uint32_t)c->nitems, &f->job) != OZG_OK) {
+	/* the devices take the batches in turn (OTEZIP_GPU_DEVICES), like the reader's windows */
+	if (ozg_use_device (g_dev0 + (int) (k % (size_t) (g_ndev > 0 ? g_ndev : 1))) != OZG_OK || ozg_encode_submit (f->b.src, c->used + 16, f->b.out, ocap + 16, f->ee, (ozg_enc_result *)f->b.res, (uint32_t)c->nitems, &f->job) != OZG_OK) {
 		fprintf (stderr, "otezip-amd: GPU encode failed: %s\n", ozg_last_error ());
 		winbuf_put (&f->b);
 		free (f->ee);
@@ -1293,6 +1294,7 @@ static int flush_pending(zip_t *za) {
 	}
 	rc = 0;
 done:
+	ozg_use_device (g_dev0);
 	for (int k = 0; k < 2; k++) {
 		if (fl[k].live) {
 			(void)ozg_job_wait (fl[k].job);
