@@ -40,7 +40,6 @@
 #define OTZ_K1_WARM 128u  // head start of walk A (bits)
 #endif
 #define OTZ_K1_SLOT (OTZ_K1_WARM / 8u + OTZ_K1_S / 8u + 12u) // slot bytes per lane: WARM/8 before + S/8 + 12 behind; 23 dwords (odd: no bank conflicts)
-                          // (a walk prefetches up to three words past its slot: the next lane's, never used)
 #define OTZ_K1_NCAP (OTZ_K1_ROWS * OTZ_IX_G) // tokens a walk may take per round
 #define OTZ_K1_HDR_WORDS 264u // staged bytes for a block header: 17 + 57 + 318 x 14 bits < 1056 bytes
 
@@ -55,14 +54,23 @@ static_assert ((OTZ_IX_G & (OTZ_IX_G - 1u)) == 0, "power of two");
                            // with Z_BUF_ERROR there (:610, :821-830), while running dry INSIDE a token is Z_DATA_ERROR
 
 // Decode tables of the index kernel: 16-bit entries, 10-bit root for the literal/length code.
-// This kernel never needs a literal's value or a match's distance -- only how many bits a
-// token takes and how many bytes it yields -- so an entry is small, a long root fits, and
-// the second-level lookup (codes longer than the root) becomes rare.
-//   lit[]:  [3:0] code length (0: no code);  bit 4: length code, then [7:5] extra-bit count,
-//           [15:8] base length - 3;  else [7:5]: 0 literal, 1 end of block, 2 invalid symbol,
-//           3 link ([3:0] index width, [15:8] (sub-table start - root size) / 2)
-//   dist[]: code length + extra-bit count (1..28), 0: invalid symbol or no code;
+// This kernel never needs a match's distance -- only how many bits a token takes and how many
+// bytes it yields -- so an entry is small, a long root fits, and the second-level lookup (codes
+// longer than the root) becomes rare.  The layout is chosen for the walk's inner loop: every
+// field it needs is one VALU instruction away, and "this lane cannot take a token here" is ONE
+// test (extra-bit field == 7).
+//   lit[]:  [3:0] code length, [6:4] X, [15:7] B
+//           X < 7: a token.  literal: X = 0, B = 1.  length code: X = extra-bit count (0..5),
+//                  B = base length (3..258): the token yields B + (X extra bits) bytes, and
+//                  B > 2 says that a distance code follows
+//           X = 7: special.  B = 0: no code / reserved symbol 286, 287 (ref deflate-dec.inc.c:794-797);
+//                  B = 1: end of block ([3:0] its code length); B >= 3: link, [3:0] index width,
+//                  B - 3 = (sub-table start - root size) / 2
+//   dist[]: code length + extra-bit count (1..28); OTZ_K1_DBAD: reserved symbol (30, 31) or no code
+//           (large: a token ending there lies beyond every limit, so the walk needs no test of its own);
 //           bit 15: link ([3:0] index width, [14:4] sub-table start - root size)
+#define OTZ_K1_SPECIAL 0x70u
+#define OTZ_K1_DBAD 0x3FFFu
 #define OTZ_K1_LROOT 10u
 #define OTZ_K1_DROOT 8u
 #ifndef OTZ_K1_LLUT
@@ -264,13 +272,13 @@ OTZ_DEV int otz_k1_parse_lengths(otz_k1_lds &L, u32 p, u64 avail, u32 n, u32 *bi
 
 OTZ_DEV u32 otz_k1_mk_lit(u32 sym, u32 len) {
 	if (sym < 256u) {
-		return len;
+		return len | (1u << 7);
 	}
 	if (sym == 256u) {
-		return len | (1u << 5);
+		return len | OTZ_K1_SPECIAL | (1u << 7);
 	}
 	if (sym > 285u) {
-		return len | (2u << 5); // ref deflate-dec.inc.c:794-797
+		return len | OTZ_K1_SPECIAL; // ref deflate-dec.inc.c:794-797
 	}
 	const u32 k = sym - 257u;
 	u32 base, xb;
@@ -284,12 +292,12 @@ OTZ_DEV u32 otz_k1_mk_lit(u32 sym, u32 len) {
 		xb = (k >> 2) - 1u;
 		base = 3u + ((4u + (k & 3u)) << xb);
 	}
-	return len | 16u | (xb << 5) | ((base - 3u) << 8);
+	return len | (xb << 4) | (base << 7);
 }
 
 OTZ_DEV u32 otz_k1_mk_dist(u32 sym, u32 len) {
 	if (sym >= 30u) {
-		return 0; // the reference indexes past dist_base[] here (:766-774)
+		return OTZ_K1_DBAD; // the reference indexes past dist_base[] here (:766-774)
 	}
 	return len + (sym < 4u ? 0u : (sym >> 1) - 1u);
 }
@@ -304,10 +312,10 @@ OTZ_DEV int otz_k1_build_tables(otz_k1_lds &L, u32 hlit, u32 hdist) {
 	const u32 lane = otz_lane ();
 	const u64 below = ((u64)1 << lane) - 1u;
 	for (u32 i = lane; i < OTZ_K1_LLUT / 2u; i += 64u) {
-		reinterpret_cast<u32 *> (L.lit)[i] = 0;
+		reinterpret_cast<u32 *> (L.lit)[i] = OTZ_K1_SPECIAL * 0x10001u; // no code
 	}
 	for (u32 i = lane; i < OTZ_K1_DLUT / 2u; i += 64u) {
-		reinterpret_cast<u32 *> (L.dist)[i] = 0;
+		reinterpret_cast<u32 *> (L.dist)[i] = OTZ_K1_DBAD * 0x10001u;
 	}
 	int st = 0;
 	for (u32 tbl = 0; tbl < 2u; tbl++) {
@@ -390,7 +398,7 @@ OTZ_DEV int otz_k1_build_tables(otz_k1_lds &L, u32 hlit, u32 hdist) {
 			const u32 tot = otz_readlane (incl, 63u);
 			const u32 off = total + incl - sz; // relative to the end of the root table; even (every size is)
 			if (sz && total + tot <= cap - rsz) {
-				lut[slot] = (u16) (tbl ? 0x8000u | (off << 4) | wd : wd | (3u << 5) | ((off >> 1) << 8));
+				lut[slot] = (u16) (tbl ? 0x8000u | (off << 4) | wd : wd | OTZ_K1_SPECIAL | ((3u + (off >> 1)) << 7));
 			}
 			total += tot;
 		}
@@ -407,7 +415,7 @@ OTZ_DEV int otz_k1_build_tables(otz_k1_lds &L, u32 hlit, u32 hdist) {
 					const u32 rr = otz_brev (f + L.h.rank[at0 + sym]) >> (32u - l);
 					const u16 e = (u16) (tbl ? otz_k1_mk_dist (sym, l) : otz_k1_mk_lit (sym, l));
 					const u32 link = lut[rr & (rsz - 1u)];
-					const u32 sb = link & 15u, sbase = rsz + (tbl ? (link >> 4) & 0x7FFu : 2u * (link >> 8));
+					const u32 sb = link & 15u, sbase = rsz + (tbl ? (link >> 4) & 0x7FFu : 2u * ((link >> 7) - 3u));
 					for (u32 idx = rr >> root; idx < (1u << sb); idx += 1u << (l - root)) {
 						lut[sbase + idx] = e;
 					}
@@ -438,74 +446,80 @@ struct otz_k1_tok {
 	u32 kind;   // 0: literal or match, 1: end of block, 2: invalid
 };
 
-// One token whose bits start at bit 0 of (hi:lo); both table lookups are issued for every lane
-// (a literal's distance lookup reads some valid entry and is ignored), so the step is
-// straight-line code but for the rare second-level lookups.
+// One token whose bits start at bit 0 of (hi:lo), in full: for everything outside the walks' loops
+// (classification of a stop, the recount of the fixpoint, the serial finisher).
 OTZ_DEV otz_k1_tok otz_k1_decode_bits(const otz_k1_lds &L, u32 lo, u32 hi) {
 	u32 e = L.lit[lo & ((1u << OTZ_K1_LROOT) - 1u)];
-	if ((e & 0xF0u) == 0x60u) {
-		e = L.lit[(1u << OTZ_K1_LROOT) + 2u * (e >> 8) + otz_bfe (lo, OTZ_K1_LROOT, e & 15u)];
+	if ((e & OTZ_K1_SPECIAL) == OTZ_K1_SPECIAL && (e >> 7) >= 3u) {
+		e = L.lit[(1u << OTZ_K1_LROOT) + 2u * ((e >> 7) - 3u) + otz_bfe (lo, OTZ_K1_LROOT, e & 15u)];
 	}
-	const u32 len = e & 15u;
-	const bool is_len = (e & 16u) != 0;
-	const u32 xb = otz_bfe (e, 5, 3); // length code: extra bits; else 0 literal, 1 end of block, 2 invalid
+	const u32 len = e & 15u, xb = otz_bfe (e, 4, 3), B = e >> 7;
+	otz_k1_tok t;
+	if (xb == 7u) {
+		t.nbits = len;
+		t.obytes = 0;
+		t.kind = B == 1u ? 1u : 2u;
+		return t;
+	}
 	const u32 used = len + xb;
 	const u32 db = otz_alignbit (hi, lo, used);
 	u32 d = L.dist[db & ((1u << OTZ_K1_DROOT) - 1u)];
 	if (d & 0x8000u) {
 		d = L.dist[(1u << OTZ_K1_DROOT) + ((d >> 4) & 0x7FFu) + otz_bfe (db, OTZ_K1_DROOT, d & 15u)];
 	}
-	otz_k1_tok t;
+	const bool is_len = B > 2u;
 	t.nbits = is_len ? used + d : len;
-	t.obytes = is_len ? (e >> 8) + 3u + otz_bfe (lo >> len, 0, xb) : 1u;
-	t.kind = is_len ? (d ? 0u : 2u) : (e ? xb : 2u);
+	t.obytes = B + otz_bfe (lo, len, xb);
+	t.kind = is_len && d >= OTZ_K1_DBAD ? 2u : 0u;
 	return t;
 }
 
-// Stateless form: three dword-aligned slot words and a funnel shift (a byte-unaligned 8-byte
-// LDS read costs 5x the LDS time).
+// three dword-aligned slot words and a funnel shift (a byte-unaligned 8-byte LDS read costs 5x the LDS time)
 OTZ_DEV otz_k1_tok otz_k1_decode(const otz_k1_lds &L, const u8 *slot, u32 u) {
 	const u32 *wp = reinterpret_cast<const u32 *> (slot) + (u >> 5);
-	const u64 w01 = otz_ld64u (wp);
-	const u32 w2 = wp[2];
-	return otz_k1_decode_bits (L, otz_alignbit ((u32) (w01 >> 32), (u32)w01, u), otz_alignbit (w2, (u32) (w01 >> 32), u));
+	const u32 w0 = wp[0], w1 = wp[1], w2 = wp[2];
+	return otz_k1_decode_bits (L, otz_alignbit (w1, w0, u), otz_alignbit (w2, w1, u));
 }
 
-// A walk keeps three slot words (96 stream bits from the word holding its position) in
-// registers and asks for the next two BEFORE it decodes: they arrive while the table lookups
-// are in flight, and the window then slides by 0-2 words to the next token -- so a step waits
-// for the two table lookups only, not for the stream.  (A token is at most 48 bits.)
-struct otz_k1_win {
-	u32 w0, w1, w2;
-	u32 a; // slot word index of w0; the walk's position lies in that word
+// The step of the walks' loops.  Both kernels of the DEFLATE decode are bound by VALU issue (a
+// wave64 VALU instruction holds its SIMD for four cycles; scalar instructions issue beside it), so
+// this is written to the instruction: ~22 VALU instructions per token --
+//   3 slot words (2: address) + 2 funnel shifts, literal/length lookup (2: address), 3 field
+//   extractions, the special test, funnel shift + distance lookup (3), B, "a distance follows"
+//   + select (2), the token's bits and bytes (3 three-operand adds / bit-field extracts).
+// Lanes leave the loops through the execution mask (scalar instructions), nothing is selected
+// per lane.  stop: no token can be taken here (end of block, reserved symbol, no such code).
+struct otz_k1_step {
+	u32 nb;   // bits of the token; beyond every limit when its distance code is reserved
+	u32 ob;   // bytes it yields
+	bool stop;
 };
-OTZ_DEV void otz_k1_win_init(otz_k1_win &W, const u8 *slot, u32 u) {
-	const u32 *sw = reinterpret_cast<const u32 *> (slot);
-	W.a = u >> 5;
-	W.w0 = sw[W.a];
-	W.w1 = sw[W.a + 1u];
-	W.w2 = sw[W.a + 2u];
-}
-// decode at u (which lies in word W.a); then slide the window to `nu` (>= u, < u + 49) with
-// otz_k1_win_slide -- in between the caller decides whether the lane takes the token at all
-struct otz_k1_pre {
-	u32 p0, p1;
-};
-OTZ_DEV otz_k1_tok otz_k1_win_decode(const otz_k1_lds &L, const u8 *slot, const otz_k1_win &W, u32 u, otz_k1_pre &P) {
-	const u64 p01 = otz_ld64u (reinterpret_cast<const u32 *> (slot) + W.a + 3u); // (4-byte aligned; beyond the slot: the next lane's, unused)
-	P.p0 = (u32)p01;
-	P.p1 = (u32) (p01 >> 32);
-	return otz_k1_decode_bits (L, otz_alignbit (W.w1, W.w0, u), otz_alignbit (W.w2, W.w1, u));
-}
-OTZ_DEV void otz_k1_win_slide(otz_k1_win &W, const otz_k1_pre &P, u32 nu) {
-	const u32 na = nu >> 5, d = na - W.a;
-	const u32 n0 = d == 0 ? W.w0 : d == 1u ? W.w1 : W.w2;
-	const u32 n1 = d == 0 ? W.w1 : d == 1u ? W.w2 : P.p0;
-	const u32 n2 = d == 0 ? W.w2 : d == 1u ? P.p0 : P.p1;
-	W.w0 = n0;
-	W.w1 = n1;
-	W.w2 = n2;
-	W.a = na;
+OTZ_DEV otz_k1_step otz_k1_hot(const otz_k1_lds &L, const u8 *slot, u32 u) {
+	const u32 *wp = reinterpret_cast<const u32 *> (slot) + otz_opaque (u >> 5); // (opaque: shift, then one shift-and-add)
+	const u32 w0 = wp[0], w1 = wp[1], w2 = wp[2];
+	const u32 lo = otz_alignbit (w1, w0, u), hi = otz_alignbit (w2, w1, u);
+	u32 e = L.lit[lo & ((1u << OTZ_K1_LROOT) - 1u)];
+	u32 xb = otz_bfe (e, 4, 3);
+	otz_k1_step r;
+	r.stop = false;
+	if (xb == 7u) { // rare: a code longer than the root, or the end of the block
+		if ((e >> 7) >= 3u) {
+			e = L.lit[(1u << OTZ_K1_LROOT) + 2u * ((e >> 7) - 3u) + otz_bfe (lo, OTZ_K1_LROOT, e & 15u)];
+			xb = otz_bfe (e, 4, 3);
+		}
+		r.stop = xb == 7u;
+	}
+	const u32 len = e & 15u, used = len + xb;
+	const u32 db = otz_alignbit (hi, lo, used);
+	u32 d = L.dist[db & ((1u << OTZ_K1_DROOT) - 1u)]; // (a literal reads some entry and ignores it)
+	const u32 B = e >> 7;
+	const bool is_len = B > 2u;
+	if (is_len && (d & 0x8000u) != 0) {
+		d = L.dist[(1u << OTZ_K1_DROOT) + ((d >> 4) & 0x7FFu) + otz_bfe (db, OTZ_K1_DROOT, d & 15u)];
+	}
+	r.nb = used + (is_len ? d : 0u);
+	r.ob = B + otz_bfe (lo, len, xb);
+	return r;
 }
 
 // How a walk that stopped at slot-relative bit u ends: the exit word.
@@ -536,83 +550,121 @@ OTZ_DEV u32 otz_k1_classify(const otz_k1_lds &L, const u8 *slot, u32 u, u32 e, u
 //     its column of `rows`, and the token starts of the segment's first 64 bits in a bitmap.
 //   !SPEC (walk B): from the lane's true start; stops as soon as it stands on walk A's path:
 //     on one of the early token starts (bmA) or on a checkpoint (rowsA / nckA).
-// The main loop counts tokens with ONE counter for the whole wavefront (every walking lane
-// takes one token per iteration), so the checkpoint cadence is a scalar branch, a row of
-// checkpoints is one coalesced store, and the body is straight-line code: a lane that has
-// stopped keeps decoding the token it stopped at and commits nothing.
+// rows / rowsA: [row][lane], the base is the same in every lane.
+// Every walking lane takes one token per iteration of the main loop, so the iteration number is
+// the token count: the checkpoint cadence is a scalar branch and a row of checkpoints is one
+// coalesced store.
+// state of a walk's main loop (registers; the loop is instantiated twice -- its first iterations
+// carry the bookkeeping of the early token starts, the steady state does not)
+struct otz_k1_ws {
+	u32 u, bytes, cnt;
+	u64 bm;
+	bool merged, capped;
+	u32 c, cpos;
+	otz_ix_item *row; // this lane's place in the next checkpoint row
+};
+
+// iterations [n0, n1) for the lanes that are still walking (the caller's execution mask); returns
+// false for a lane that has stopped
+template <bool SPEC, bool EARLY>
+OTZ_DEV bool otz_k1_walk_span(const otz_k1_lds &L, const u8 *slot, otz_k1_ws &W, u32 n0, u32 n1, u32 s, u32 e, u32 lim2, const otz_ix_item *rowsA, u64 bmA, u32 nckA) {
+	const u32 lane = otz_lane ();
+	for (u32 n = n0; n < n1; n++) {
+		if (!SPEC) {
+			while (W.cpos < W.u) { // (rare: passed a checkpoint of walk A without landing on it)
+				W.c++;
+				W.cpos = W.c < nckA ? rowsA[W.c * 64u + lane].bit : OTZ_K1_NONE;
+			}
+			bool hit = W.cpos == W.u;
+			if (EARLY) { // the early token starts of walk A
+				const u32 rel = W.u - s;
+				hit = hit || (rel < 64u && ((bmA >> rel) & 1u) != 0);
+			}
+			if (hit) {
+				W.merged = true;
+				W.capped = false;
+				return false;
+			}
+		}
+		if (SPEC && EARLY) {
+			const u32 rel = W.u - s;
+			if (rel < 64u) {
+				W.bm |= (u64)1 << rel;
+			}
+		}
+		if ((n & (OTZ_IX_G - 1u)) == 0) {
+			otz_ix_item k;
+			k.bit = W.u;
+			k.out = W.bytes;
+			*W.row = k;
+			W.row += 64u; // (here, not per iteration: the address arithmetic is VALU work too)
+		}
+		const otz_k1_step h = otz_k1_hot (L, slot, W.u);
+		const u32 tend = W.u + h.nb;
+		if (h.stop || tend > lim2) {
+			W.capped = false;
+			return false;
+		}
+		W.u = tend;
+		W.bytes += h.ob;
+		W.cnt = n + 1u;
+		if (tend >= e) {
+			W.capped = false;
+			return false;
+		}
+	}
+	return true;
+}
+
 template <bool SPEC>
 OTZ_DEV otz_k1_path otz_k1_walk(const otz_k1_lds &L, const u8 *slot, bool run, u32 start, u32 s, u32 e, u32 limit,
 	otz_ix_item *rows, const otz_ix_item *rowsA, u64 bmA, u32 nckA) {
+	const u32 lane = otz_lane ();
+	// a token that starts in front of e ends in front of e + 48: the clamp changes nothing for
+	// tokens that exist and puts a reserved distance code (OTZ_K1_DBAD bits) beyond the limit
+	const u32 lim2 = limit < e + 48u ? limit : e + 48u;
 	otz_k1_path P;
-	u32 u = run ? start : s; // (lanes that do not walk still execute the straight-line body: keep them inside the slot)
+	otz_k1_ws W;
+	W.u = run ? start : s;
 	bool alive = run;
-	otz_k1_win W;
-	otz_k1_pre PF;
-	otz_k1_win_init (W, slot, u);
 	if (SPEC) {
-		while (alive && u < s) {
-			const otz_k1_tok t = otz_k1_win_decode (L, slot, W, u, PF);
-			const u32 tend = u + t.nbits;
-			alive = t.kind == 0 && tend <= limit;
-			u = alive ? tend : u;
-			otz_k1_win_slide (W, PF, u);
+		if (alive) {
+			while (W.u < s) {
+				const otz_k1_step h = otz_k1_hot (L, slot, W.u);
+				const u32 tend = W.u + h.nb;
+				if (h.stop || tend > lim2) {
+					alive = false;
+					break;
+				}
+				W.u = tend;
+			}
 		}
 	}
-	const u32 first = alive ? u : OTZ_K1_NONE;
-	u32 cnt = 0, bytes = 0;
-	u64 bm = 0;
-	bool merged = false;
-	u32 c = 1, cpos = OTZ_K1_NONE; // walk B: walk A's next checkpoint at or behind u (row 0 is its first token: bmA has it)
+	const u32 first = alive ? W.u : OTZ_K1_NONE;
+	W.cnt = W.bytes = 0;
+	W.bm = 0;
+	W.merged = W.capped = false;
+	W.c = 1; // walk B: walk A's next checkpoint at or behind u (row 0 is its first token: bmA has it)
+	W.cpos = OTZ_K1_NONE;
+	W.row = rows + lane;
 	if (!SPEC) {
-		cpos = run && nckA > 1u ? rowsA[64u].bit : OTZ_K1_NONE;
+		W.cpos = run && nckA > 1u ? rowsA[64u + lane].bit : OTZ_K1_NONE;
 	}
-	bool active = alive;
-	for (u32 n = 0; n < OTZ_K1_NCAP; n++) {
-		if (!SPEC) {
-			while (active && cpos < u) { // (rare: passed a checkpoint of walk A without landing on it)
-				c++;
-				cpos = c < nckA ? rowsA[c * 64u].bit : OTZ_K1_NONE;
-			}
-			bool hit = cpos == u;
-			if (n < 16u) { // the early token starts of walk A
-				const u32 rel = u - s;
-				hit = hit || (rel < 64u && ((bmA >> rel) & 1u) != 0);
-			}
-			merged = merged || (active && hit);
-			active = active && !merged;
-		}
-		if (SPEC && n < 8u) {
-			const u32 rel = u - s;
-			bm |= active && rel < 64u ? (u64)1 << rel : 0u;
-		}
-		if ((n & (OTZ_IX_G - 1u)) == 0) {
-			if (active) {
-				otz_ix_item k;
-				k.bit = u;
-				k.out = bytes;
-				rows[n * (64u / OTZ_IX_G)] = k; // row n / G of the lane's column
-			}
-		}
-		const otz_k1_tok t = otz_k1_win_decode (L, slot, W, u, PF);
-		const u32 tend = u + t.nbits;
-		const bool adv = active && t.kind == 0 && tend <= limit;
-		u = adv ? tend : u;
-		otz_k1_win_slide (W, PF, u);
-		cnt += adv ? 1u : 0u;
-		bytes += adv ? t.obytes : 0u;
-		active = adv && u < e;
-		if (otz_ballot (active) == 0) {
-			break;
+	if (alive) {
+		W.capped = true;
+		constexpr u32 NE = SPEC ? 8u : 16u;
+		if (otz_k1_walk_span<SPEC, true> (L, slot, W, 0, NE, s, e, lim2, rowsA, bmA, nckA)) {
+			(void)otz_k1_walk_span<SPEC, false> (L, slot, W, NE, OTZ_K1_NCAP, s, e, lim2, rowsA, bmA, nckA);
 		}
 	}
-	P.exit = alive && !merged ? otz_k1_classify (L, slot, u, e, limit, active) : OTZ_X_MAKE (OTZ_X_INVALID, u);
-	P.n = cnt;
-	P.bytes = bytes;
+	P.exit = alive && !W.merged ? otz_k1_classify (L, slot, W.u, e, limit, W.capped) : OTZ_X_MAKE (OTZ_X_INVALID, W.u);
+	P.n = W.cnt;
+	P.bytes = W.bytes;
 	P.first = first;
-	P.tstart = u;
-	P.bm = bm;
-	P.mpos = merged ? u : OTZ_K1_NONE;
-	P.mrow = merged && cpos == u ? c : OTZ_K1_NONE;
+	P.tstart = W.u;
+	P.bm = W.bm;
+	P.mpos = W.merged ? W.u : OTZ_K1_NONE;
+	P.mrow = W.merged && W.cpos == W.u ? W.c : OTZ_K1_NONE;
 	return P;
 }
 
@@ -668,8 +720,8 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 		status = OTZ_IX_OVERFLOW;
 	}
 	const u32 rec_limit = region_bytes >= OTZ_K1_TEMP_BYTES + 1024u ? region_bytes - OTZ_K1_TEMP_BYTES : 0u;
-	// checkpoint rows of the two walks, [row][lane]; this lane's column
-	otz_ix_item *const rowsA = reinterpret_cast<otz_ix_item *> (region + rec_limit) + lane;
+	// checkpoint rows of the two walks, [row][lane]
+	otz_ix_item *const rowsA = reinterpret_cast<otz_ix_item *> (region + rec_limit); // (the same in every lane)
 	otz_ix_item *const rowsB = rowsA + OTZ_K1_ROWS * 64u;
 
 	while (status == 0 && !ended) {
@@ -849,12 +901,6 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 				if (otz_ballot (rewalk) != 0) {
 					OTZ_K1_COUNT (8);
 					const otz_k1_path W = otz_k1_walk<false> (L, slot, rewalk, nt, s, e, limit, rowsB, rowsA, A.bm, nckA);
-#ifdef OTZ_K1_STATS
-					if (rewalk) {
-						fprintf (stderr, "rewalk it=%u lane=%u nt=%u Afirst=%d An=%u Wn=%u mpos=%d mrow=%d Aexit=%x Wexit=%x\n", it, lane, nt - s, (int) (A.first - s), A.n, W.n,
-							(int) (W.mpos == OTZ_K1_NONE ? -1 : (int) (W.mpos - s)), (int)W.mrow, A.exit, W.exit);
-					}
-#endif
 					// where on walk A's path did it land: count walk A's tokens up to there
 					const bool early = rewalk && W.mpos != OTZ_K1_NONE && W.mrow == OTZ_K1_NONE;
 					u32 x = A.first, j = 0, ob = 0;
@@ -871,7 +917,7 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 						onA = W.mpos != OTZ_K1_NONE;
 						mp = W.mpos;
 						jm = early ? j : W.mrow * OTZ_IX_G;
-						offA = early ? ob : onA ? rowsA[W.mrow * 64u].out : 0u;
+						offA = early ? ob : onA ? rowsA[W.mrow * 64u + lane].out : 0u;
 						exit_cur = onA ? A.exit : W.exit;
 					}
 				}
@@ -936,7 +982,7 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 #pragma unroll 2
 					for (u32 r = 0; r < OTZ_K1_ROWS; r++) {
 						if (acc && r < nB_items) {
-							otz_ix_item it = rowsB[r * 64u];
+							otz_ix_item it = rowsB[r * 64u + lane];
 							it.bit += bit0;
 							it.out += obase;
 							dst[r] = it;
@@ -952,7 +998,7 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 #pragma unroll 4
 				for (u32 r = 1; r < OTZ_K1_ROWS; r++) {
 					if (acc && tailA && r >= rA0 && r < nckA) {
-						otz_ix_item it = rowsA[r * 64u];
+						otz_ix_item it = rowsA[r * 64u + lane];
 						it.bit += bit0;
 						it.out += obase + bytesB - offA;
 						dst[nB_items + 1u + r - rA0] = it;
