@@ -22,78 +22,86 @@
 // output byte at absolute position o_abs.  Literals go to their final ring bytes (and are
 // marked final); a match is parked in the first three bytes of its own destination (23 bits:
 // distance-1 : 15, length-3 : 8 -- a match is at least three bytes long) and its destination
-// is noted.  The loop is unrolled: every lane runs the same OTZ_IX_G steps, three aligned stage
-// words and the two table lookups each, no loop-carried window.
+// is noted.  The kernel is bound by VALU issue, so the loop is written to the instruction: lanes
+// leave it, and take the literal or the match branch, through the execution mask (scalar
+// instructions) -- nothing is computed for a lane and then selected away -- and a step reloads
+// its three stage words instead of sliding a window (~55 VALU instructions per token; the
+// unrolled select-based form took 129).
 // Afterwards the destinations of all matches of the round are written, in stream order, to
 // `list` (round-relative, u16): a prefix sum over the lanes' match counts gives every lane its
 // slice.  Returns the number of matches of the round.  All OTZ_NT work-items.
-static_assert (OTZ_IX_G == 8u, "eight 16-bit destinations are packed into two 64-bit registers");
+static_assert (OTZ_IX_G == 8u, "eight 16-bit destinations are packed into four 32-bit registers");
 static_assert (OTZ_NT * OTZ_IX_G * 2u <= OTZ_STAGE_BYTES, "the match list of a round fits the stage buffer");
+static_assert (OTZ_RMAX <= 65536u, "round-relative positions fit 16 bits");
 OTZ_DEV u32 otz_place_items(otz_inflate_lds &L, bool active, u32 s_bit, u32 e_bit, u32 o_abs, u32 round_base, u16 *list) {
-	u32 pos = s_bit;
-	u32 rel = active ? o_abs - round_base : 0u; // round-relative output position
-	u32 ri = OTZ_RIDX (active ? o_abs : round_base);
-	u32 curw = rel >> 5, finm = 0;
 	u32 nm = 0;
-	u64 pk_lo = 0, pk_hi = 0;
-	bool bad = false, too_far = false;
-	otz_win W;
-	otz_win_init (W, L, pos);
-#pragma unroll
-	for (u32 i = 0; i < OTZ_IX_G; i++) {
-		const bool act = active && pos < e_bit && !bad;
-		// (three stage words in registers, the next two asked for before the lookups: otz_win)
-		const u32 p0 = L.stage_w[W.a + 3u], p1 = L.stage_w[W.a + 4u];
-		const otz_tok t = otz_decode_bits (L, otz_alignbit (W.w1, W.w0, pos), otz_alignbit (W.w2, W.w1, pos));
-		const bool lit = t.kind == OTZ_K_LIT, mat = t.kind == OTZ_K_LEN;
-		// (the index kernel validated the chain: anything else here is an internal error)
-		bad = bad || (act && !lit && !mat);
-		// ref reads window bytes nobody wrote (:524): no parity, fail cleanly
-		too_far = too_far || (act && mat && t.dist > round_base + rel);
-		const bool put = act && (lit || mat) && !too_far;
-		const u32 wd = rel >> 5;
-		if (put && wd != curw) {
-			otz_lds_or (&L.fin[curw], finm);
-			curw = wd;
-			finm = 0;
-		}
-		const u32 d = (t.dist - 1u) | ((t.val - 3u) << 15); // the parked match
-		if (put) {
-			L.ring[ri] = (u8) (lit ? t.val : d);
-			if (mat) {
-				L.ring[OTZ_RWRAP (ri + 1u)] = (u8) (d >> 8);
-				L.ring[OTZ_RWRAP (ri + 2u)] = (u8) (d >> 16);
+	u32 k0 = 0, k1 = 0, k2 = 0, k3 = 0; // the matches' destinations, newest in the low half of k0
+	u32 err = 0;                        // 1: the index and the stream disagree, 2: distance beyond the output start
+	u32 pos = s_bit;
+	if (active) {
+		u32 rel = o_abs - round_base; // round-relative output position
+		u32 ri = OTZ_RIDX (o_abs);
+		for (u32 i = 0; i < OTZ_IX_G; i++) {
+			if (pos >= e_bit) {
+				break;
+			}
+			const u32 *wp = &L.stage_w[otz_opaque (pos >> 5)];
+			const u32 w0 = wp[0], w1 = wp[1], w2 = wp[2];
+			const u32 lo = otz_alignbit (w1, w0, pos), hi = otz_alignbit (w2, w1, pos);
+			const u32 e = otz_lut2<OTZ_LIT_ROOT> (L.lit_lut, lo);
+			const u32 len = e & 15u, kind = (e >> 4) & 3u;
+			if (kind == OTZ_K_LIT) {
+				L.ring[ri] = (u8) (e >> 16);
+				otz_lds_or (&L.fin[rel >> 5], 1u << (rel & 31u));
+				rel += 1u;
+				ri = ri + 1u == OTZ_RING ? 0u : ri + 1u;
+				pos += len;
+			} else if (kind == OTZ_K_LEN) {
+				const u32 xb = (e >> 8) & 15u;
+				const u32 val = (e >> 16) + otz_bfe (lo, len, xb);
+				const u32 used = len + xb; // <= 20
+				const u32 db = otz_alignbit (hi, lo, used);
+				const u32 d = otz_lut2<OTZ_DIST_ROOT> (L.dist_lut, db);
+				const u32 dl = d & 15u, dxb = (d >> 8) & 15u; // dl + dxb <= 28
+				if (((d >> 4) & 3u) != OTZ_K_LEN) {
+					err = 1; // (the index kernel validated the chain: an internal error)
+					break;
+				}
+				const u32 dist = (d >> 16) + otz_bfe (db, dl, dxb);
+				if (dist > round_base + rel) {
+					err = 2; // ref reads window bytes nobody wrote (:524): no parity, fail cleanly
+					break;
+				}
+				const u32 cd = (dist - 1u) | ((val - 3u) << 15); // the parked match
+				if (ri + 2u < OTZ_RING) {
+					L.ring[ri] = (u8)cd;
+					L.ring[ri + 1u] = (u8) (cd >> 8);
+					L.ring[ri + 2u] = (u8) (cd >> 16);
+				} else {
+					L.ring[ri] = (u8)cd;
+					L.ring[OTZ_RWRAP (ri + 1u)] = (u8) (cd >> 8);
+					L.ring[OTZ_RWRAP (ri + 2u)] = (u8) (cd >> 16);
+				}
+				k3 = otz_alignbit (k3, k2, 16);
+				k2 = otz_alignbit (k2, k1, 16);
+				k1 = otz_alignbit (k1, k0, 16);
+				k0 = (k0 << 16) | rel;
+				nm += 1u;
+				rel += val;
+				ri = OTZ_RWRAP (ri + val);
+				pos += used + dl + dxb;
+			} else {
+				err = 1;
+				break;
 			}
 		}
-		finm |= put && lit ? 1u << (rel & 31u) : 0u;
-		{
-			const u64 v = (u64)rel << (16u * (nm & 3u));
-			const bool m = put && mat;
-			pk_lo |= m && nm < 4u ? v : 0u;
-			pk_hi |= m && nm >= 4u ? v : 0u;
-			nm += m ? 1u : 0u;
-		}
-		const u32 adv = lit ? 1u : t.val;
-		rel += put ? adv : 0u;
-		ri = put ? OTZ_RWRAP (ri + adv) : ri;
-		pos += put ? t.nbits : 0u;
-		{
-			const u32 na = pos >> 5, dd = na - W.a; // a token is at most 48 bits: 0-2 words further
-			const u32 n0 = dd == 0 ? W.w0 : dd == 1u ? W.w1 : W.w2;
-			const u32 n1 = dd == 0 ? W.w1 : dd == 1u ? W.w2 : p0;
-			const u32 n2 = dd == 0 ? W.w2 : dd == 1u ? p0 : p1;
-			W.w0 = n0;
-			W.w1 = n1;
-			W.w2 = n2;
-			W.a = na;
+		if (err == 0 && pos != e_bit) {
+			err = 1;
 		}
 	}
-	if (finm) {
-		otz_lds_or (&L.fin[curw], finm);
-	}
-	if (too_far) {
+	if (err == 2u) {
 		otz_set_status (L, OZG_ST_DATA);
-	} else if (bad || (active && pos != e_bit)) {
+	} else if (err != 0) {
 		L.dbg[0] = 2; // the index and the stream disagree
 		L.dbg[1] = otz_tid ();
 		L.dbg[2] = pos;
@@ -103,10 +111,12 @@ OTZ_DEV u32 otz_place_items(otz_inflate_lds &L, bool active, u32 s_bit, u32 e_bi
 	u32 total;
 	const u32 incl = otz_block_scan_incl (nm, L.scan, &total); // (two barriers: every stage read is done)
 	const u32 at = incl - nm;
+	// match number q (in stream order) is the (nm - 1 - q)-th newest
 #pragma unroll
-	for (u32 q = 0; q < OTZ_IX_G; q++) {
-		if (q < nm) {
-			list[at + q] = (u16) ((q < 4u ? pk_lo : pk_hi) >> (16u * (q & 3u)));
+	for (u32 k = 0; k < OTZ_IX_G; k++) {
+		if (k < nm) {
+			const u32 w = k < 2u ? k0 : k < 4u ? k1 : k < 6u ? k2 : k3;
+			list[at + nm - 1u - k] = (u16) (w >> (16u * (k & 1u)));
 		}
 	}
 	return total;
