@@ -100,6 +100,17 @@ def pmc_traffic(entries, entry_bytes, method):
     return best
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
 def cpu_baseline(arc, ent, sample_entries):
     """Reference (oracle/_ref/ref_bench, built from /root/reference in the build container)
     timed on this box's host cores over the first `sample_entries` entries of the same
@@ -124,7 +135,7 @@ def cpu_baseline(arc, ent, sample_entries):
         nbytes = sum(int(o[1]) for o in outs)
         nulls = sum(int(o[3]) for o in outs)
         worker_max = max(float(o[2]) for o in outs)
-        return {"value": nbytes / worker_max / 2**30, "unit": "GiB/s", "cores": cores, "kind": "reference",
+        return {"value": nbytes / worker_max / 2**30, "unit": "GiB/s", "cores": cores, "kind": "reference", "cpu": cpu_model(),
                 "sample": "first %d of the same 64 KiB DEFLATE entries, zip_fopen_index+zip_fclose, %d processes "
                           "x independent zip_open, wall %.1fs, reference NULL entries %d" % (n, cores, wall, nulls)}
     from oracle import pyoracle as O
@@ -135,7 +146,7 @@ def cpu_baseline(arc, ent, sample_entries):
         r = O.extract_entry(int(m), arc[off:off + cs], int(us), int(crc))
         nbytes += len(r["out"])
     dt = time.time() - t0
-    return {"value": nbytes / dt / 2**30, "unit": "GiB/s", "cores": 1, "kind": "port",
+    return {"value": nbytes / dt / 2**30, "unit": "GiB/s", "cores": 1, "kind": "port", "cpu": cpu_model(),
             "sample": "first %d entries through the C restatement oracle/otz_oracle.c (reference build absent)" % n}
 
 
@@ -245,7 +256,8 @@ def main():
         kavg = sum(kernel_ms) / len(kernel_ms) * 1e-3
         algo = comp_bytes + out_bytes
         line = {
-            "metric": "decompressed GiB/s, batched DEFLATE extract (zip_fopen_index path), 64 KiB entries",
+            "metric": "decompressed GiB/s, batched DEFLATE decode of an HBM-resident batch (ozg_decode_batch_device_ex: the kernel span "
+                      "behind zip_fopen_index), 64 KiB entries",
             "value": round(value, 3), "unit": "GiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong" if strong else "weak",

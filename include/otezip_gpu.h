@@ -97,7 +97,10 @@ typedef struct ozg_limits {
 /* One context per device.  ozg_init(d) prepares device d and makes it the calling thread's
  * current one; a host that drives several GPUs of a node calls it once per device and then
  * picks the device of the following calls with ozg_use_device(d) (per thread).  ozg_shutdown
- * releases every context. */
+ * releases every context.  Device numbers are LOGICAL: with OTEZIP_GPU_DEVICE_MAP="0,0,1" in the
+ * environment logical devices 0 and 1 are two independent contexts on physical GPU 0 and logical 2 is
+ * one on GPU 1 (ozg_device_count() then returns 3); without it logical = physical.  A thread that has
+ * not chosen starts on the device of the process's first successful ozg_init. */
 int ozg_init(int device);
 int ozg_use_device(int device);
 int ozg_current_device(void);
@@ -185,6 +188,13 @@ int ozg_encode_batch_host(const void *src, uint64_t src_len, void *dst, uint64_t
  * zip_close's batched writer drives): one job = H2D of the sources, otezip_compress_data
  * (ref src/lib/otezip.c:788-1076) + CRC-32 (:1124) for every buffer, D2H.  Pinned buffers. */
 int ozg_encode_submit(const void *h_src, uint64_t src_len, void *h_dst, uint64_t dst_len,
+	const ozg_enc_entry *entries, ozg_enc_result *h_results, uint32_t n, ozg_job **job);
+/* The same, with the outputs PACKED on the device before they cross PCIe: after ozg_job_wait the
+ * payload of entry i starts at the sum over j < i of ((h_results[j].comp_size + 15) & ~15) (entries whose
+ * status is not OZG_ST_OK take no room) instead of at dst_off[i].  dst_off / dst_cap still describe the
+ * device-side slots; h_dst needs room for the packed bytes only (at most dst_len).  What the batched
+ * writer of zip_close uses: the worst-case slot layout is 2-3 x the bytes that matter. */
+int ozg_encode_submit_packed(const void *h_src, uint64_t src_len, void *h_dst, uint64_t dst_len,
 	const ozg_enc_entry *entries, ozg_enc_result *h_results, uint32_t n, ozg_job **job);
 
 /* crc[i] = CRC-32 of d_buf[off[i] .. off[i]+len[i]) (all device pointers). */

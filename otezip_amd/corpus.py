@@ -11,6 +11,7 @@ payloads, central directory, EOCD) with the field layout the reference parses
 (ref src/lib/otezip.c:360-378, :429-437).
 """
 import multiprocessing as mp
+import os
 import struct
 import zlib
 
@@ -110,10 +111,48 @@ def _make_one(args):
     return idx, method, _ENCODERS[method](data), len(data), zlib.crc32(data) & 0xFFFFFFFF
 
 
+def _cache_path(tag):
+    """Generated corpora are kept on local disk (OTEZIP_BENCH_CACHE, default /tmp/otezip_amd_cache): a
+    tool that runs under rocprofv3 must not fork a worker pool (the profiler has initialised the GPU
+    in that process), so profiling scripts generate in an unprofiled step and the profiled one loads."""
+    d = os.environ.get("OTEZIP_BENCH_CACHE", "/tmp/otezip_amd_cache")
+    try:
+        os.makedirs(d, exist_ok=True)
+    except OSError:
+        return None
+    return os.path.join(d, tag + ".pkl")
+
+
+def _cached(tag, make, min_items, n):
+    import pickle
+    path = _cache_path(tag) if n >= min_items else None
+    if path and os.path.exists(path):
+        try:
+            with open(path, "rb") as f:
+                return pickle.load(f)
+        except Exception:
+            pass
+    val = make()
+    if path:
+        try:
+            tmp = "%s.tmp%d" % (path, os.getpid())
+            with open(tmp, "wb") as f:
+                pickle.dump(val, f, protocol=4)
+            os.replace(tmp, path)
+        except OSError:
+            pass
+    return val
+
+
 def build_archive(n, size, methods=(8,), workers=None, first=0):
     """Generate n entries (entry i uses methods[i % len(methods)]) and serialise a ZIP32
     archive image.  Returns (archive_bytes, entries) with entries =
-    [dict(name, method, data_off, comp_size, uncomp_size, crc32)]."""
+    [dict(name, method, data_off, comp_size, uncomp_size, crc32)].  Large corpora are cached on disk."""
+    tag = "arc_v3_n%d_s%d_m%s_f%d" % (n, size, "-".join(str(m) for m in methods), first)
+    return _cached(tag, lambda: _build_archive(n, size, methods, workers, first), 1000, n)
+
+
+def _build_archive(n, size, methods, workers, first):
     jobs = [(first + i, size, methods[i % len(methods)]) for i in range(n)]
     if workers is None:
         workers = min(mp.cpu_count(), 16)
@@ -149,6 +188,10 @@ def _text_one(args):
 
 def text_buffers(n, size, first=0, workers=None):
     """The n uncompressed buffers of the corpus (what build_archive compresses), for the encode side."""
+    return _cached("txt_v3_n%d_s%d_f%d" % (n, size, first), lambda: _text_buffers(n, size, first, workers), 1000, n)
+
+
+def _text_buffers(n, size, first, workers):
     jobs = [(first + i, size) for i in range(n)]
     if workers is None:
         workers = min(mp.cpu_count(), 16)

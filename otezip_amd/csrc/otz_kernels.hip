@@ -267,6 +267,58 @@ otz_enc_crc_kernel(const u8 *src, u8 *dst, const ozg_enc_entry *entries, ozg_enc
 	}
 }
 
+// Packing the outputs of an encode batch before they cross PCIe: the encode kernel writes every
+// payload at its worst-case slot (dst_off, dst_cap = compressBound), so the batch's output buffer is
+// 2-3x the bytes that matter.  otz_pack_scan_kernel (one workgroup) gives entry i the running
+// 16-byte-aligned offset pack_off[i] (pack_off[n] = total); otz_pack_copy_kernel moves the payloads.
+extern "C" __global__ void __launch_bounds__ (256)
+otz_pack_scan_kernel(const ozg_enc_result *results, u32 n, u64 *pack_off) {
+	__shared__ u64 part[256];
+	const u32 t = threadIdx.x;
+	const u32 per = (n + 255u) / 256u;
+	const u32 i0 = t * per < n ? t * per : n, i1 = i0 + per < n ? i0 + per : n;
+	u64 sum = 0;
+	for (u32 i = i0; i < i1; i++) {
+		sum += ((u64)(results[i].status == OZG_ST_OK ? results[i].comp_size : 0u) + 15u) & ~(u64)15u;
+	}
+	part[t] = sum;
+	__syncthreads ();
+	if (t == 0) {
+		u64 run = 0;
+		for (u32 k = 0; k < 256u; k++) {
+			const u64 v = part[k];
+			part[k] = run;
+			run += v;
+		}
+		pack_off[n] = run;
+	}
+	__syncthreads ();
+	u64 at = part[t];
+	for (u32 i = i0; i < i1; i++) {
+		pack_off[i] = at;
+		at += ((u64)(results[i].status == OZG_ST_OK ? results[i].comp_size : 0u) + 15u) & ~(u64)15u;
+	}
+}
+
+extern "C" __global__ void __launch_bounds__ (256)
+otz_pack_copy_kernel(const u8 *dst, const ozg_enc_entry *entries, const ozg_enc_result *results, const u64 *pack_off, u8 *packed, u32 n, u64 dst_len) {
+	const u32 i = blockIdx.x;
+	if (i >= n || results[i].status != OZG_ST_OK) {
+		return;
+	}
+	const ozg_enc_entry e = entries[i];
+	const u32 m = results[i].comp_size;
+	if ((e.dst_off & 15u) != 0 || e.dst_off > dst_len || (u64)m > dst_len - e.dst_off) {
+		return; // (the encode kernel refused such a descriptor: status is not OK; belt and braces)
+	}
+	const u8 *from = dst + e.dst_off;
+	u8 *to = packed + pack_off[i];
+	const u32 chunks = (m + 15u) >> 4; // both sides are 16-byte aligned; the slot is at least that long rounded up
+	for (u32 c = threadIdx.x; c < chunks; c += 256u) {
+		otz_st16_aligned (to + 16u * c, otz_ld16_aligned (from + 16u * c));
+	}
+}
+
 // ------------------------------------------------------------------ host side
 //
 // One context per HIP device (staging buffers, the index arena, the slots of the asynchronous
@@ -278,7 +330,7 @@ otz_enc_crc_kernel(const u8 *src, u8 *dst, const ozg_enc_entry *entries, ozg_enc
 namespace {
 
 constexpr int MAX_DEV = 16;
-constexpr int N_SLOTS = 3; // asynchronous staged batches in flight per device
+constexpr int N_SLOTS = 8; // asynchronous staged batches in flight per device (a full table is back-pressure for the caller: OZG_E_NOMEM)
 
 std::mutex g_mu; // contexts, their buffers and slots
 u32 g_chunks = 1; // chunks of a large DEFLATE batch on two internal streams (OTEZIP_GPU_CHUNKS; 0 = cut at a whole number of index-kernel generations): neither measured faster than one launch pair (4.13 ms; 4 chunks 4.43, generation cut 4.14), kept for experiments
@@ -287,10 +339,41 @@ u64 *g_prof = nullptr; // diagnostics: per-entry phase cycle counters (ozg_debug
 thread_local char g_err[256] = "";
 thread_local int g_cur = -1; // this thread's device (ozg_init / ozg_use_device)
 int g_default = -1;          // the device of the first successful ozg_init: what a thread starts with
+// Device numbers of this ABI are LOGICAL: OTEZIP_GPU_DEVICE_MAP="0,0,1" makes logical devices 0 and 1
+// two independent contexts (buffers, arena, job slots, streams) on physical device 0 and logical 2 one
+// on physical 1.  Without the variable logical = physical.  (What it is for: running the multi-device
+// paths of the zip layer -- dealing, per-device arenas, job ownership -- on a box with one GPU.)
+int g_phys[16];
+int g_nlogical = -1; // -1: map not read yet; 0: no map
+int phys_of(int d) { return g_nlogical > 0 ? g_phys[d] : d; }
+void read_device_map() {
+	if (g_nlogical >= 0) {
+		return;
+	}
+	g_nlogical = 0;
+	const char *m = getenv ("OTEZIP_GPU_DEVICE_MAP");
+	if (!m || !*m) {
+		return;
+	}
+	int n = 0;
+	while (*m && n < 16) {
+		char *end = nullptr;
+		long v = strtol (m, &end, 10);
+		if (end == m || v < 0 || v > 1023) {
+			break;
+		}
+		g_phys[n++] = (int)v;
+		m = *end == ',' ? end + 1 : end;
+		if (*end != ',' ) {
+			break;
+		}
+	}
+	g_nlogical = n;
+}
 
 struct staging {
-	void *d_src = nullptr, *d_dst = nullptr, *d_ent = nullptr, *d_res = nullptr;
-	size_t src_cap = 0, dst_cap = 0, ent_cap = 0, res_cap = 0;
+	void *d_src = nullptr, *d_dst = nullptr, *d_ent = nullptr, *d_res = nullptr, *d_pack = nullptr;
+	size_t src_cap = 0, dst_cap = 0, ent_cap = 0, res_cap = 0, pack_cap = 0;
 };
 
 // Index arena of the DEFLATE path; batches on different streams are ordered through `done`.
@@ -323,8 +406,14 @@ struct ozg_job {
 	hipStream_t stream = nullptr;
 	hipEvent_t done = nullptr;
 	staging st;
-	void *h_ent = nullptr; // pinned copy of the descriptor table
+	void *h_ent = nullptr; // pinned copy of the descriptor table (+ 64 bytes: the packed total comes back there)
 	size_t h_ent_cap = 0;
+	// packed encode batches finish in two steps: results + total first (mid), then exactly `total` bytes
+	bool two_step = false;
+	hipEvent_t mid = nullptr;
+	void *h_dst = nullptr;
+	uint64_t dst_len = 0;
+	size_t total_at = 0; // byte offset of the u64 total inside h_ent
 };
 
 namespace {
@@ -358,7 +447,7 @@ int need_ctx(dev_ctx **out) {
 		snprintf (g_err, sizeof (g_err), "ozg_init() has not succeeded: no HIP device, and this library has no CPU path");
 		return OZG_E_NODEVICE;
 	}
-	OZG_HIP (hipSetDevice (d));
+	OZG_HIP (hipSetDevice (phys_of (d)));
 	g_cur = d;
 	*out = &g_dev[d];
 	return OZG_OK;
@@ -384,6 +473,7 @@ void staging_free(staging &s) {
 	(void)hipFree (s.d_dst);
 	(void)hipFree (s.d_ent);
 	(void)hipFree (s.d_res);
+	(void)hipFree (s.d_pack);
 	s = staging ();
 }
 
@@ -571,6 +661,16 @@ int ozg_device_count(void) {
 	if (hipGetDeviceCount (&n) != hipSuccess) {
 		return 0;
 	}
+	std::lock_guard<std::mutex> lk (g_mu);
+	read_device_map ();
+	if (g_nlogical > 0) {
+		for (int k = 0; k < g_nlogical; k++) {
+			if (g_phys[k] >= n) {
+				return k; // (logical devices up to the first one that names a GPU the node does not have)
+			}
+		}
+		return g_nlogical;
+	}
 	return n;
 }
 
@@ -583,11 +683,12 @@ int ozg_init(int device) {
 			e == hipSuccess ? "device count 0" : hipGetErrorString (e));
 		return OZG_E_NODEVICE;
 	}
-	if (device < 0 || device >= n || device >= MAX_DEV) {
-		snprintf (g_err, sizeof (g_err), "device %d out of range (0..%d)", device, (n < MAX_DEV ? n : MAX_DEV) - 1);
+	read_device_map ();
+	if (device < 0 || device >= MAX_DEV || (g_nlogical > 0 ? device >= g_nlogical || g_phys[device] >= n : device >= n)) {
+		snprintf (g_err, sizeof (g_err), "device %d out of range (%d HIP device(s)%s)", device, n, g_nlogical > 0 ? ", OTEZIP_GPU_DEVICE_MAP in force" : "");
 		return OZG_E_ARG;
 	}
-	OZG_HIP (hipSetDevice (device));
+	OZG_HIP (hipSetDevice (phys_of (device)));
 	if (!g_dev[device].ready) {
 		// (function attributes are per device)
 		OZG_HIP (hipFuncSetAttribute ((const void *)otz_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -609,7 +710,7 @@ int ozg_init(int device) {
 		OZG_HIP (hipFuncSetAttribute ((const void *)otz_encode_prof_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
 			(int)sizeof (otz_enc_lds)));
 		int cus = 256, per_cu = 16;
-		(void)hipDeviceGetAttribute (&cus, hipDeviceAttributeMultiprocessorCount, device);
+		(void)hipDeviceGetAttribute (&cus, hipDeviceAttributeMultiprocessorCount, phys_of (device));
 		(void)hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu, otz_index_kernel, 64, sizeof (otz_k1_lds));
 		g_dev[device].gen = (u32) (cus > 0 ? cus : 256) * (u32) (per_cu > 0 ? per_cu : 16);
 		per_cu = 8;
@@ -634,7 +735,7 @@ int ozg_use_device(int device) {
 		snprintf (g_err, sizeof (g_err), "device %d has not been initialised with ozg_init()", device);
 		return OZG_E_ARG;
 	}
-	OZG_HIP (hipSetDevice (device));
+	OZG_HIP (hipSetDevice (phys_of (device)));
 	g_cur = device;
 	return OZG_OK;
 }
@@ -648,7 +749,7 @@ void ozg_shutdown(void) {
 		if (!C.ready) {
 			continue;
 		}
-		if (hipSetDevice (d) != hipSuccess) {
+		if (hipSetDevice (phys_of (d)) != hipSuccess) {
 			continue;
 		}
 		(void)hipDeviceSynchronize ();
@@ -665,6 +766,9 @@ void ozg_shutdown(void) {
 			}
 			if (j.done) {
 				(void)hipEventDestroy (j.done);
+			}
+			if (j.mid) {
+				(void)hipEventDestroy (j.mid);
 			}
 			j = ozg_job ();
 		}
@@ -833,9 +937,17 @@ int ozg_decode_submit(const void *h_src, uint64_t src_len, void *h_dst, uint64_t
 	return OZG_OK;
 }
 
-// the encode side of the same pipeline: H2D, encode + CRC kernels, D2H on the job's stream
-int ozg_encode_submit(const void *h_src, uint64_t src_len, void *h_dst, uint64_t dst_len, const ozg_enc_entry *entries,
-	ozg_enc_result *h_results, uint32_t n, ozg_job **job) {
+// the launches of one encode batch on stream s (device pointers); the caller holds g_mu
+static int launch_encode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, uint64_t dst_len, const ozg_enc_entry *d_entries,
+	ozg_enc_result *d_results, uint32_t n, hipStream_t s);
+
+// the encode side of the same pipeline: H2D, encode + CRC kernels, D2H on the job's stream.
+// packed: the payloads come back back to back (entry i at the running sum of its predecessors'
+// comp_size, each rounded up to 16) instead of at dst_off[i]: the device packs them first and only
+// the bytes that matter cross PCIe (in two steps: results and the total, then the payloads;
+// ozg_job_wait runs the second step).
+static int encode_submit(const void *h_src, uint64_t src_len, void *h_dst, uint64_t dst_len, const ozg_enc_entry *entries,
+	ozg_enc_result *h_results, uint32_t n, ozg_job **job, bool packed) {
 	dev_ctx *C;
 	int rc = need_ctx (&C);
 	if (rc != OZG_OK) {
@@ -864,39 +976,81 @@ int ozg_encode_submit(const void *h_src, uint64_t src_len, void *h_dst, uint64_t
 		OZG_HIP (hipStreamCreateWithFlags (&J->stream, hipStreamNonBlocking));
 		OZG_HIP (hipEventCreateWithFlags (&J->done, hipEventDisableTiming));
 	}
+	if (!J->mid) {
+		OZG_HIP (hipEventCreateWithFlags (&J->mid, hipEventDisableTiming));
+	}
 	J->dev = g_cur;
+	J->two_step = false;
 	const size_t ent_bytes = (size_t)n * sizeof (ozg_enc_entry);
 	if ((rc = staging_reserve (J->st, src_len + 64, dst_len + 64, ent_bytes, (size_t)n * sizeof (ozg_enc_result))) != OZG_OK) {
 		return rc;
 	}
-	if (ent_bytes > J->h_ent_cap) {
+	const size_t off_bytes = ((size_t)n + 1u) * sizeof (u64);
+	if (packed && (rc = grow (&J->st.d_pack, &J->st.pack_cap, dst_len + 64 + off_bytes + 64)) != OZG_OK) {
+		return rc;
+	}
+	if (ent_bytes + 64 > J->h_ent_cap) {
 		if (J->h_ent) {
 			(void)hipHostFree (J->h_ent);
 			J->h_ent = nullptr;
 			J->h_ent_cap = 0;
 		}
-		OZG_HIP (hipHostMalloc (&J->h_ent, ent_bytes + (ent_bytes >> 1), hipHostMallocDefault));
-		J->h_ent_cap = ent_bytes + (ent_bytes >> 1);
+		OZG_HIP (hipHostMalloc (&J->h_ent, ent_bytes + (ent_bytes >> 1) + 64, hipHostMallocDefault));
+		J->h_ent_cap = ent_bytes + (ent_bytes >> 1) + 64;
 	}
 	memcpy (J->h_ent, entries, ent_bytes);
 	hipStream_t s = J->stream;
 	OZG_HIP (hipMemcpyAsync (J->st.d_src, h_src, src_len, hipMemcpyHostToDevice, s));
 	OZG_HIP (hipMemcpyAsync (J->st.d_ent, J->h_ent, ent_bytes, hipMemcpyHostToDevice, s));
-	rc = ozg_encode_batch_device (J->st.d_src, src_len, J->st.d_dst, dst_len, (const ozg_enc_entry *)J->st.d_ent, (ozg_enc_result *)J->st.d_res, n, s);
+	rc = launch_encode (*C, J->st.d_src, src_len, J->st.d_dst, dst_len, (const ozg_enc_entry *)J->st.d_ent, (ozg_enc_result *)J->st.d_res, n, s);
 	if (rc != OZG_OK) {
 		return rc;
 	}
-	OZG_HIP (hipMemcpyAsync (h_dst, J->st.d_dst, dst_len, hipMemcpyDeviceToHost, s));
-	OZG_HIP (hipMemcpyAsync (h_results, J->st.d_res, (size_t)n * sizeof (ozg_enc_result), hipMemcpyDeviceToHost, s));
-	OZG_HIP (hipEventRecord (J->done, s));
+	if (packed) {
+		// offsets live behind the packed payload area (16-byte aligned)
+		u8 *pk = (u8 *)J->st.d_pack;
+		u64 *d_off = (u64 *) (pk + ((dst_len + 64u + 15u) & ~(uint64_t)15u));
+		hipLaunchKernelGGL (otz_pack_scan_kernel, dim3 (1), dim3 (256), 0, s, (const ozg_enc_result *)J->st.d_res, n, d_off);
+		OZG_HIP (hipGetLastError ());
+		hipLaunchKernelGGL (otz_pack_copy_kernel, dim3 (n), dim3 (256), 0, s, (const u8 *)J->st.d_dst, (const ozg_enc_entry *)J->st.d_ent,
+			(const ozg_enc_result *)J->st.d_res, (const u64 *)d_off, pk, n, (u64)dst_len);
+		OZG_HIP (hipGetLastError ());
+		J->total_at = (ent_bytes + 15u) & ~(size_t)15u;
+		if (J->total_at + 8u > J->h_ent_cap) {
+			J->total_at = J->h_ent_cap - 8u;
+		}
+		OZG_HIP (hipMemcpyAsync ((u8 *)J->h_ent + J->total_at, d_off + n, sizeof (u64), hipMemcpyDeviceToHost, s));
+		OZG_HIP (hipMemcpyAsync (h_results, J->st.d_res, (size_t)n * sizeof (ozg_enc_result), hipMemcpyDeviceToHost, s));
+		OZG_HIP (hipEventRecord (J->mid, s));
+		J->two_step = true;
+		J->h_dst = h_dst;
+		J->dst_len = dst_len;
+	} else {
+		OZG_HIP (hipMemcpyAsync (h_dst, J->st.d_dst, dst_len, hipMemcpyDeviceToHost, s));
+		OZG_HIP (hipMemcpyAsync (h_results, J->st.d_res, (size_t)n * sizeof (ozg_enc_result), hipMemcpyDeviceToHost, s));
+		OZG_HIP (hipEventRecord (J->done, s));
+	}
 	J->busy = true;
 	*job = J;
 	return OZG_OK;
 }
 
+int ozg_encode_submit(const void *h_src, uint64_t src_len, void *h_dst, uint64_t dst_len, const ozg_enc_entry *entries,
+	ozg_enc_result *h_results, uint32_t n, ozg_job **job) {
+	return encode_submit (h_src, src_len, h_dst, dst_len, entries, h_results, n, job, false);
+}
+
+int ozg_encode_submit_packed(const void *h_src, uint64_t src_len, void *h_dst, uint64_t dst_len, const ozg_enc_entry *entries,
+	ozg_enc_result *h_results, uint32_t n, ozg_job **job) {
+	return encode_submit (h_src, src_len, h_dst, dst_len, entries, h_results, n, job, true);
+}
+
 int ozg_job_done(ozg_job *job) {
 	if (!job || !job->busy) {
 		return 1;
+	}
+	if (job->two_step) {
+		return 0; // (its payload copy is only issued by ozg_job_wait)
 	}
 	return hipEventQuery (job->done) == hipSuccess ? 1 : 0;
 }
@@ -906,19 +1060,39 @@ int ozg_job_wait(ozg_job *job) {
 		return OZG_OK;
 	}
 	const int keep = g_cur;
-	if (hipSetDevice (job->dev) != hipSuccess) {
+	if (hipSetDevice (phys_of (job->dev)) != hipSuccess) {
 		return OZG_E_HIP;
 	}
-	hipError_t e = hipEventSynchronize (job->done);
+	hipError_t e = hipSuccess;
+	if (job->two_step) {
+		e = hipEventSynchronize (job->mid);
+		if (e == hipSuccess) {
+			uint64_t total = 0;
+			memcpy (&total, (const u8 *)job->h_ent + job->total_at, sizeof (total));
+			if (total > job->dst_len) {
+				total = job->dst_len; // (cannot happen: every payload fits its slot)
+			}
+			if (total) {
+				e = hipMemcpyAsync (job->h_dst, job->st.d_pack, (size_t)total, hipMemcpyDeviceToHost, job->stream);
+			}
+			if (e == hipSuccess) {
+				e = hipEventRecord (job->done, job->stream);
+			}
+		}
+	}
+	if (e == hipSuccess) {
+		e = hipEventSynchronize (job->done);
+	}
 	{
 		std::lock_guard<std::mutex> lk (g_mu);
 		job->busy = false;
+		job->two_step = false;
 	}
 	if (keep >= 0 && keep != job->dev) {
-		(void)hipSetDevice (keep);
+		(void)hipSetDevice (phys_of (keep));
 	}
 	if (e != hipSuccess) {
-		return fail_hip ("hipEventSynchronize", e);
+		return fail_hip ("ozg_job_wait", e);
 	}
 	return OZG_OK;
 }
@@ -936,23 +1110,10 @@ uint64_t ozg_compress_bound(uint16_t method, uint64_t n) {
 	return b < 16u ? 16u : b;
 }
 
-int ozg_encode_batch_device(const void *d_src, uint64_t src_len, void *d_dst, uint64_t dst_len,
-	const ozg_enc_entry *d_entries, ozg_enc_result *d_results, uint32_t n, void *stream) {
-	dev_ctx *C;
-	int rc = need_ctx (&C);
-	if (rc != OZG_OK) {
-		return rc;
-	}
-	if (n == 0) {
-		return OZG_OK;
-	}
-	if (!d_src || !d_dst || !d_entries || !d_results || ((uintptr_t)d_dst & 15u)) {
-		snprintf (g_err, sizeof (g_err), "null device pointer or d_dst not 16-byte aligned");
-		return OZG_E_ARG;
-	}
-	hipStream_t s = (hipStream_t)stream;
-	workspace &ws = C->ws;
-	const u32 ENC_GRID = C->enc_grid;
+static int launch_encode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, uint64_t dst_len, const ozg_enc_entry *d_entries,
+	ozg_enc_result *d_results, uint32_t n, hipStream_t s) {
+	workspace &ws = C.ws;
+	const u32 ENC_GRID = C.enc_grid;
 	const u32 grid = n < ENC_GRID ? n : ENC_GRID;
 	if (!ws.enc_done) {
 		OZG_HIP (hipEventCreateWithFlags (&ws.enc_done, hipEventDisableTiming));
@@ -983,6 +1144,24 @@ int ozg_encode_batch_device(const void *d_src, uint64_t src_len, void *d_dst, ui
 	return OZG_OK;
 }
 
+int ozg_encode_batch_device(const void *d_src, uint64_t src_len, void *d_dst, uint64_t dst_len,
+	const ozg_enc_entry *d_entries, ozg_enc_result *d_results, uint32_t n, void *stream) {
+	dev_ctx *C;
+	int rc = need_ctx (&C);
+	if (rc != OZG_OK) {
+		return rc;
+	}
+	if (n == 0) {
+		return OZG_OK;
+	}
+	if (!d_src || !d_dst || !d_entries || !d_results || ((uintptr_t)d_dst & 15u)) {
+		snprintf (g_err, sizeof (g_err), "null device pointer or d_dst not 16-byte aligned");
+		return OZG_E_ARG;
+	}
+	std::lock_guard<std::mutex> lk (g_mu); // (the token scratch and its event belong to the device's workspace)
+	return launch_encode (*C, d_src, src_len, d_dst, dst_len, d_entries, d_results, n, (hipStream_t)stream);
+}
+
 int ozg_encode_batch_host(const void *src, uint64_t src_len, void *dst, uint64_t dst_len,
 	const ozg_enc_entry *entries, ozg_enc_result *results, uint32_t n) {
 	dev_ctx *C;
@@ -1007,7 +1186,7 @@ int ozg_encode_batch_host(const void *src, uint64_t src_len, void *dst, uint64_t
 	}
 	OZG_HIP (hipMemcpyAsync (S.d_src, src, src_len, hipMemcpyHostToDevice, nullptr));
 	OZG_HIP (hipMemcpyAsync (S.d_ent, entries, (size_t)n * sizeof (ozg_enc_entry), hipMemcpyHostToDevice, nullptr));
-	rc = ozg_encode_batch_device (S.d_src, src_len, S.d_dst, dst_len, (const ozg_enc_entry *)S.d_ent, (ozg_enc_result *)S.d_res, n, nullptr);
+	rc = launch_encode (*C, S.d_src, src_len, S.d_dst, dst_len, (const ozg_enc_entry *)S.d_ent, (ozg_enc_result *)S.d_res, n, nullptr);
 	if (rc != OZG_OK) {
 		return rc;
 	}

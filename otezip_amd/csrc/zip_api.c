@@ -47,6 +47,8 @@
 #define WIN_MAX_COMP (48ull << 20)
 #define WIN_MAX_OUT (96ull << 20)
 #define READ_THREADS 4 /* a window's stretch of the file is read by this many pread()s in parallel */
+#define AHEAD_MAX 8    /* windows prepared ahead of a sequential reader: one per device (OTEZIP_GPU_DEVICES), at most this many */
+#define FLIGHTS_MAX (AHEAD_MAX + 1) /* encode batches in flight while a flush writes: one per device + the one being written */
 /* Pending adds are flushed at this many source bytes / entries: the ZIP32 limits, so that in
  * practice a batch lives until zip_close (or until one of its entries is needed) and
  * zip_set_file_compression reaches every entry added since. */
@@ -79,6 +81,11 @@ struct window {
 	long readers;              /* open zip_file_t that point into b.out */
 	int detached;              /* no longer one of the archive's windows */
 	struct ozh_zip *owner;
+	/* a read-ahead window is filled (file read, local headers, submit) by a helper thread */
+	pthread_t th;
+	int th_live;
+	int quiet;                 /* read-ahead: a failure is not reported, the reader starts over when it gets there */
+	struct win_fill *fill;
 };
 
 struct pend_item {
@@ -97,7 +104,9 @@ struct pchunk {
 
 struct ozh_zip {
 	struct zip pub; /* MUST stay first: callers see this prefix */
-	struct window *win, *ahead; /* current window, and the one being prepared behind it */
+	struct window *win;         /* current window */
+	struct window *ahead[AHEAD_MAX]; /* the ones being prepared behind it, in index order */
+	int n_ahead;
 	zip_uint64_t last_index;
 	unsigned seq_hits;     /* consecutive opens of index, index + 1, ... */
 	zip_uint64_t grow;     /* size of the next read-ahead window */
@@ -141,7 +150,8 @@ static int g_gpu_state; /* 0 untried, 1 ok, -1 failed */
 static int g_ndev = 1, g_dev0 = 0;
 
 /* OTEZIP_GPU_DEVICE = first device (default 0), OTEZIP_GPU_DEVICES = how many consecutive
- * devices the windows of an archive are dealt to (default 1) */
+ * devices the windows of an archive are dealt to (default 1); device numbers are the logical ones
+ * of otezip_gpu.h (OTEZIP_GPU_DEVICE_MAP) */
 static pthread_mutex_t g_gpu_mu = PTHREAD_MUTEX_INITIALIZER;
 static int gpu_up(void) {
 	pthread_mutex_lock (&g_gpu_mu);
@@ -156,8 +166,12 @@ static int gpu_up(void) {
 		if (have > 0 && g_dev0 + want > have) {
 			want = have > g_dev0 ? have - g_dev0 : 1;
 		}
+		if (want > AHEAD_MAX) {
+			want = AHEAD_MAX;
+		}
 		g_ndev = 0;
-		for (int k = want - 1; k >= 0; k--) { /* (device g_dev0 last: it stays the current one) */
+		/* first device first: it becomes the default of every thread that has not chosen one */
+		for (int k = 0; k < want; k++) {
 			int rc = ozg_init (g_dev0 + k);
 			if (rc != OZG_OK) {
 				fprintf (stderr, "otezip-amd: %s\n", ozg_last_error ());
@@ -167,9 +181,10 @@ static int gpu_up(void) {
 					return 0;
 				}
 				want = k;
-				continue;
+				break;
 			}
 		}
+		(void)ozg_use_device (g_dev0);
 		g_ndev = want;
 		g_gpu_state = 1;
 		TRACE ("devices ready: %d from %d", g_ndev, g_dev0);
@@ -470,7 +485,7 @@ static void winbuf_free(struct winbuf *b) {
 /* Pinned buffer sets outlive their windows and their archives: a process-wide pool (pinning
  * is the expensive part of the whole ingest path).  Guarded by a mutex: archives may be used
  * from different threads. */
-#define POOL_SETS 4
+#define POOL_SETS (AHEAD_MAX + 4)
 static struct winbuf g_pool[POOL_SETS];
 static pthread_mutex_t g_pool_mu = PTHREAD_MUTEX_INITIALIZER;
 
@@ -509,10 +524,12 @@ static void winbuf_put(struct winbuf *b) {
 	}
 }
 
+static void window_join(struct window *w);
 static void window_free(struct window *w) {
 	if (!w) {
 		return;
 	}
+	window_join (w);
 	if (w->job) {
 		ozg_job_wait (w->job); /* the copies still write into its buffers */
 		w->job = NULL;
@@ -698,6 +715,7 @@ static int finalize(zip_t *za) {
 }
 
 static int flush_pending(zip_t *za);
+static int flush_pending_ex(zip_t *za, int is_replace);
 static void pending_drop(struct ozh_zip *z);
 
 int zip_close(zip_t *za) {
@@ -708,6 +726,9 @@ int zip_close(zip_t *za) {
 	}
 	struct ozh_zip *z = (struct ozh_zip *)za;
 	int rc = 0;
+	for (int k = 0; k < z->n_ahead; k++) {
+		window_join (z->ahead[k]); /* (a helper thread reads this archive's directory and file) */
+	}
 	if (za->mode == 1) {
 		if (flush_pending (za) != 0 || z->write_failed) {
 			rc = -1;
@@ -726,11 +747,11 @@ int zip_close(zip_t *za) {
 	if (z->win) {
 		z->win->owner = NULL;
 	}
-	if (z->ahead) {
-		z->ahead->owner = NULL;
-	}
 	window_detach (z->win);
-	window_detach (z->ahead);
+	for (int k = 0; k < z->n_ahead; k++) {
+		z->ahead[k]->owner = NULL;
+		window_detach (z->ahead[k]);
+	}
 	pending_drop (z);
 	free (z->pch);
 	free (z->pit);
@@ -812,82 +833,27 @@ static int host_zipbomb(const struct otezip_entry *e) {
 	return (uint64_t)e->uncomp_size > (uint64_t)e->comp_size * otezip_max_expansion_ratio + otezip_max_expansion_slack;
 }
 
-/* Start decoding entries [first, first + up to want): read their bytes, submit the batch.
- * Returns the window with its job in flight (window_wait completes it), or NULL. */
-static struct window *window_begin_ex(zip_t *za, zip_uint64_t first, zip_uint64_t want, int packed_only) {
-	struct ozh_zip *z = (struct ozh_zip *)za;
-	if (za->mode == 1) {
-		fflush (za->fp);
-	}
-	if (fseek (za->fp, 0, SEEK_END) != 0) {
-		return NULL;
-	}
-	long fsl = ftell (za->fp);
-	if (fsl < 0) {
-		return NULL;
-	}
-	const uint64_t fsz = (uint64_t)fsl;
-	/* how far does the window reach */
-	zip_uint64_t count = 0;
-	uint64_t comp = 0, out = 0;
-	while (first + count < za->n_entries && count < want && count < WIN_MAX_ENTRIES && !is_pending (za, first + count)) {
-		const struct otezip_entry *e = &za->entries[first + count];
-		uint64_t c = e->comp_size, o = host_zipbomb (e) ? 0 : ((uint64_t)e->uncomp_size + 15u) & ~15ull;
-		if (count > 0 && (comp + c > WIN_MAX_COMP || out + o > WIN_MAX_OUT)) {
-			break;
-		}
-		comp += c;
-		out += o;
-		count++;
-	}
-	if (count == 0) {
-		return NULL;
-	}
-	struct window *w = (struct window *)calloc (1, sizeof (*w));
-	ozg_entry *ents = (ozg_entry *)calloc (count, sizeof (ozg_entry));
-	if (!w || !ents) {
-		free (w);
-		free (ents);
-		return NULL;
-	}
-	w->owner = z;
-	w->first = first;
-	w->count = count;
-	w->off = (uint64_t *)calloc (count, sizeof (uint64_t));
-	w->res = (ozg_result *)calloc (count, sizeof (ozg_result));
-	w->valid = (uint8_t *)calloc (count, 1);
-	w->slot = (uint32_t *)calloc (count, sizeof (uint32_t));
-	if (!w->off || !w->res || !w->valid || !w->slot) {
-		goto fail;
-	}
-	/* Entries written in index order sit back to back: then ONE read covers local headers and
-	 * payloads of the window, and the headers are parsed from the buffer.  Anything else (entries
-	 * rewritten by zip_file_replace, foreign layouts) is read entry by entry into a packed buffer. */
-	uint64_t lo = za->entries[first].local_hdr_ofs, hi;
-	int one_span = !packed_only;
-	for (zip_uint64_t k = 1; k < count && one_span; k++) {
-		one_span = za->entries[first + k].local_hdr_ofs > za->entries[first + k - 1].local_hdr_ofs;
-	}
-	if (first + count < za->n_entries && !is_pending (za, first + count)) {
-		hi = za->entries[first + count].local_hdr_ofs;
-	} else {
-		hi = za->mode == 0 && z->cd_ofs ? z->cd_ofs : fsz;
-	}
-	if (hi > fsz) {
-		hi = fsz;
-	}
-	if (one_span && (hi <= za->entries[first + count - 1].local_hdr_ofs || hi - lo > comp + count * 2048ull + (1u << 20))) {
-		one_span = 0;
-	}
-	const size_t src_need = (size_t) (one_span ? hi - lo : comp + 16u * count) + 64;
-	TRACE ("window [%llu, +%llu): %s, %llu B in, %llu B out", (unsigned long long)first, (unsigned long long)count,
-		one_span ? "one read" : "entry by entry", (unsigned long long)src_need, (unsigned long long)out);
-	if (winbuf_get (z, &w->b, src_need, (size_t)out + 64, count) != 0) {
-		fprintf (stderr, "otezip-amd: %s\n", ozg_last_error ());
-		goto fail;
-	}
+/* what filling a window needs once it is planned: the file stretch, the batch under construction */
+struct win_fill {
+	zip_t *za;
+	uint64_t fsz, lo, hi, out;
+	int one_span;
+	int dev;
+	ozg_entry *ents;
+};
+
+/* Second half of window_begin: read the window's bytes, check the local headers (ref otezip.c:411-446),
+ * submit the batch.  Runs on the caller's thread, or on a helper thread for a read-ahead window of a
+ * read-only archive (then only pread() on the descriptor is used: the FILE's position belongs to the
+ * caller).  Returns 0, -1, or 1: "the layout is not what the one-read path assumes, take the packed road". */
+static int window_fill(struct window *w) {
+	struct win_fill *F = w->fill;
+	zip_t *za = F->za;
+	const zip_uint64_t first = w->first, count = w->count;
+	const uint64_t fsz = F->fsz, lo = F->lo, hi = F->hi;
+	const int one_span = F->one_span;
 	if (one_span && read_span (za->fp, w->b.src, lo, hi - lo) != 0) {
-		goto fail;
+		return -1;
 	}
 	TRACE ("window [%llu): bytes read", (unsigned long long)first);
 	uint32_t nb = 0;
@@ -928,10 +894,7 @@ static struct window *window_begin_ex(zip_t *za, zip_uint64_t first, zip_uint64_
 		uint64_t src_off;
 		if (one_span) {
 			if (d + e->comp_size > hi) {
-				/* the payload reaches past the stretch that was read: take the slow road for the window */
-				free (ents);
-				window_free (w);
-				return window_begin_ex (za, first, want, 1);
+				return 1; /* the payload reaches past the stretch that was read */
 			}
 			src_off = d - lo;
 		} else {
@@ -943,7 +906,7 @@ static struct window *window_begin_ex(zip_t *za, zip_uint64_t first, zip_uint64_
 		}
 		w->valid[k] = 1;
 		w->slot[k] = nb;
-		ozg_entry *b = &ents[nb++];
+		ozg_entry *b = &F->ents[nb++];
 		b->src_off = src_off;
 		b->dst_off = w->off[k];
 		b->comp_size = e->comp_size;
@@ -955,31 +918,188 @@ static struct window *window_begin_ex(zip_t *za, zip_uint64_t first, zip_uint64_
 	if (nb > 0) {
 		ozg_limits lim = { otezip_max_expansion_ratio, otezip_max_expansion_slack };
 		ozg_set_limits (&lim);
-		/* the devices take the windows in turn */
-		int dev = g_dev0 + (z->next_dev++ % (g_ndev > 0 ? g_ndev : 1));
-		int rc = ozg_use_device (dev);
+		const uint64_t src_len = (one_span ? hi - lo : packed) + 16u, dst_len = F->out + 16u;
+		int rc = ozg_use_device (F->dev);
 		if (rc == OZG_OK) {
-			rc = ozg_decode_submit (w->b.src, (one_span ? hi - lo : packed) + 16u, w->b.out, out + 16u, ents, w->b.res, nb, &w->job);
+			rc = ozg_decode_submit (w->b.src, src_len, w->b.out, dst_len, F->ents, w->b.res, nb, &w->job);
+		}
+		if (rc == OZG_E_NOMEM) {
+			/* every staged-batch slot of the device is taken (other archives walk their windows too):
+			 * back-pressure, not an error.  A read-ahead window gives up quietly -- the reader starts
+			 * over when it gets there -- and a window somebody waits for takes the synchronous call. */
+			if (w->quiet) {
+				return -1;
+			}
+			TRACE ("window [%llu): no free slot, synchronous batch", (unsigned long long)first);
+			w->job = NULL;
+			rc = ozg_decode_batch_host (w->b.src, src_len, w->b.out, dst_len, F->ents, w->b.res, nb);
+			if (rc == OZG_OK) {
+				for (zip_uint64_t k = 0; k < count; k++) {
+					if (w->valid[k] && w->slot[k] != UINT32_MAX) {
+						w->res[k] = w->b.res[w->slot[k]];
+					}
+				}
+			}
 		}
 		if (rc != OZG_OK) {
-			fprintf (stderr, "otezip-amd: GPU decode failed: %s\n", ozg_last_error ());
+			if (!w->quiet) {
+				fprintf (stderr, "otezip-amd: GPU decode failed: %s\n", ozg_last_error ());
+			}
+			return -1;
+		}
+	}
+	TRACE ("window [%llu): submitted %u entries", (unsigned long long)first, nb);
+	return 0;
+}
+
+static void win_fill_free(struct window *w) {
+	if (w->fill) {
+		free (w->fill->ents);
+		free (w->fill);
+		w->fill = NULL;
+	}
+}
+
+static void *window_fill_thread(void *p) {
+	struct window *w = (struct window *)p;
+	if (window_fill (w) != 0) {
+		w->failed = 1;
+	}
+	return NULL;
+}
+
+/* the helper thread of a read-ahead window is done after this */
+static void window_join(struct window *w) {
+	if (w->th_live) {
+		pthread_join (w->th, NULL);
+		w->th_live = 0;
+	}
+	win_fill_free (w);
+}
+
+/* Start decoding entries [first, first + up to want): read their bytes, submit the batch.
+ * ahead: a read-ahead window -- filled by a helper thread where that is safe, quiet about failures.
+ * Returns the window with its job in flight (window_wait completes it), or NULL. */
+static struct window *window_begin_ex(zip_t *za, zip_uint64_t first, zip_uint64_t want, int packed_only, int ahead) {
+	struct ozh_zip *z = (struct ozh_zip *)za;
+	if (za->mode == 1) {
+		fflush (za->fp);
+	}
+	uint64_t fsz;
+	if (za->mode == 0) {
+		struct stat sb; /* (a helper thread may be reading: leave the FILE's position alone) */
+		if (fstat (fileno (za->fp), &sb) != 0) {
+			return NULL;
+		}
+		fsz = (uint64_t)sb.st_size;
+	} else {
+		if (fseek (za->fp, 0, SEEK_END) != 0) {
+			return NULL;
+		}
+		long fsl = ftell (za->fp);
+		if (fsl < 0) {
+			return NULL;
+		}
+		fsz = (uint64_t)fsl;
+	}
+	/* how far does the window reach */
+	zip_uint64_t count = 0;
+	uint64_t comp = 0, out = 0;
+	while (first + count < za->n_entries && count < want && count < WIN_MAX_ENTRIES && !is_pending (za, first + count)) {
+		const struct otezip_entry *e = &za->entries[first + count];
+		uint64_t c = e->comp_size, o = host_zipbomb (e) ? 0 : ((uint64_t)e->uncomp_size + 15u) & ~15ull;
+		if (count > 0 && (comp + c > WIN_MAX_COMP || out + o > WIN_MAX_OUT)) {
+			break;
+		}
+		comp += c;
+		out += o;
+		count++;
+	}
+	if (count == 0) {
+		return NULL;
+	}
+	struct window *w = (struct window *)calloc (1, sizeof (*w));
+	struct win_fill *F = (struct win_fill *)calloc (1, sizeof (*F));
+	if (!w || !F) {
+		free (w);
+		free (F);
+		return NULL;
+	}
+	w->fill = F;
+	w->owner = z;
+	w->first = first;
+	w->count = count;
+	w->quiet = ahead;
+	F->za = za;
+	F->ents = (ozg_entry *)calloc (count, sizeof (ozg_entry));
+	w->off = (uint64_t *)calloc (count, sizeof (uint64_t));
+	w->res = (ozg_result *)calloc (count, sizeof (ozg_result));
+	w->valid = (uint8_t *)calloc (count, 1);
+	w->slot = (uint32_t *)calloc (count, sizeof (uint32_t));
+	if (!F->ents || !w->off || !w->res || !w->valid || !w->slot) {
+		goto fail;
+	}
+	/* Entries written in index order sit back to back: then ONE read covers local headers and
+	 * payloads of the window, and the headers are parsed from the buffer.  Anything else (entries
+	 * rewritten by zip_file_replace, foreign layouts) is read entry by entry into a packed buffer. */
+	uint64_t lo = za->entries[first].local_hdr_ofs, hi;
+	int one_span = !packed_only;
+	for (zip_uint64_t k = 1; k < count && one_span; k++) {
+		one_span = za->entries[first + k].local_hdr_ofs > za->entries[first + k - 1].local_hdr_ofs;
+	}
+	if (first + count < za->n_entries && !is_pending (za, first + count)) {
+		hi = za->entries[first + count].local_hdr_ofs;
+	} else {
+		hi = za->mode == 0 && z->cd_ofs ? z->cd_ofs : fsz;
+	}
+	if (hi > fsz) {
+		hi = fsz;
+	}
+	if (one_span && (hi <= za->entries[first + count - 1].local_hdr_ofs || hi - lo > comp + count * 2048ull + (1u << 20))) {
+		one_span = 0;
+	}
+	const size_t src_need = (size_t) (one_span ? hi - lo : comp + 16u * count) + 64;
+	TRACE ("window [%llu, +%llu): %s, %llu B in, %llu B out%s", (unsigned long long)first, (unsigned long long)count,
+		one_span ? "one read" : "entry by entry", (unsigned long long)src_need, (unsigned long long)out, ahead ? " (ahead)" : "");
+	if (winbuf_get (z, &w->b, src_need, (size_t)out + 64, count) != 0) {
+		if (!ahead) {
+			fprintf (stderr, "otezip-amd: %s\n", ozg_last_error ());
+		}
+		goto fail;
+	}
+	F->fsz = fsz;
+	F->lo = lo;
+	F->hi = hi;
+	F->out = out;
+	F->one_span = one_span;
+	/* the devices take the windows in turn */
+	F->dev = g_dev0 + (z->next_dev++ % (g_ndev > 0 ? g_ndev : 1));
+	if (ahead && one_span && za->mode == 0 && pthread_create (&w->th, NULL, window_fill_thread, w) == 0) {
+		w->th_live = 1; /* the caller's thread goes on consuming the current window meanwhile */
+		return w;
+	}
+	{
+		const int rc = window_fill (w);
+		if (rc == 1) {
+			window_free (w);
+			return window_begin_ex (za, first, want, 1, ahead);
+		}
+		if (rc != 0) {
 			goto fail;
 		}
 	}
-	free (ents);
-	TRACE ("window [%llu): submitted %u entries", (unsigned long long)first, nb);
+	win_fill_free (w);
 	return w;
 fail:
-	free (ents);
-	w->owner = z;
 	window_free (w);
 	return NULL;
 }
 
-static struct window *window_begin(zip_t *za, zip_uint64_t first, zip_uint64_t want) { return window_begin_ex (za, first, want, 0); }
+static struct window *window_begin(zip_t *za, zip_uint64_t first, zip_uint64_t want) { return window_begin_ex (za, first, want, 0, 0); }
 
 /* the window's outputs and results are in host memory after this */
 static int window_wait(struct window *w) {
+	window_join (w);
 	if (w->failed) {
 		return -1;
 	}
@@ -989,7 +1109,9 @@ static int window_wait(struct window *w) {
 		TRACE ("window [%llu): ready", (unsigned long long)w->first);
 		w->job = NULL;
 		if (rc != OZG_OK) {
-			fprintf (stderr, "otezip-amd: GPU decode failed: %s\n", ozg_last_error ());
+			if (!w->quiet) {
+				fprintf (stderr, "otezip-amd: GPU decode failed: %s\n", ozg_last_error ());
+			}
 			w->failed = 1;
 			return -1;
 		}
@@ -1007,8 +1129,11 @@ static int in_window(const struct window *w, zip_uint64_t index) { return w && i
 /* forget every decoded window (the archive's bytes changed) */
 static void windows_drop(struct ozh_zip *z) {
 	window_detach (z->win);
-	window_detach (z->ahead);
-	z->win = z->ahead = NULL;
+	z->win = NULL;
+	for (int k = 0; k < z->n_ahead; k++) {
+		window_detach (z->ahead[k]);
+	}
+	z->n_ahead = 0;
 	z->seq_hits = 0;
 }
 
@@ -1025,43 +1150,74 @@ zip_file_t *zip_fopen_index(zip_t *za, zip_uint64_t index, zip_flags_t flags) {
 	if (za->mode == 1 && is_pending (za, index) && flush_pending (za) != 0) {
 		return NULL;
 	}
-	z->seq_hits = (z->win || z->ahead) && index == z->last_index + 1 ? z->seq_hits + 1 : 0;
+	z->seq_hits = (z->win || z->n_ahead) && index == z->last_index + 1 ? z->seq_hits + 1 : 0;
 	z->last_index = index;
-	if (!in_window (z->win, index)) {
-		if (in_window (z->ahead, index)) {
-			window_detach (z->win);
-			z->win = z->ahead;
-			z->ahead = NULL;
-		} else {
-			windows_drop (z);
-			z->grow = WIN_FIRST_ENTRIES;
-			const zip_uint64_t start = index & ~(zip_uint64_t) (WIN_FIRST_ENTRIES - 1u);
-			z->win = window_begin (za, start, WIN_FIRST_ENTRIES);
-			if (z->win && !in_window (z->win, index)) { /* (a byte limit ended the window before the entry) */
+	struct window *w = NULL;
+	for (int attempt = 0; attempt < 2 && !w; attempt++) {
+		if (!in_window (z->win, index)) {
+			int hit = -1;
+			for (int k = 0; k < z->n_ahead && hit < 0; k++) {
+				hit = in_window (z->ahead[k], index) ? k : -1;
+			}
+			if (hit >= 0) {
+				/* the reader has arrived at a prepared window (the ones it skipped go) */
 				window_detach (z->win);
-				z->win = NULL;
-			}
-			if (!z->win && start != index) {
-				z->win = window_begin (za, index, WIN_FIRST_ENTRIES);
-			}
-			if (!z->win) {
-				z->win = window_begin (za, index, 1); /* (an odd layout: one entry at a time) */
-			}
-			if (!z->win) {
-				return NULL;
+				for (int k = 0; k < hit; k++) {
+					window_detach (z->ahead[k]);
+				}
+				z->win = z->ahead[hit];
+				z->n_ahead -= hit + 1;
+				memmove (z->ahead, z->ahead + hit + 1, (size_t)z->n_ahead * sizeof (z->ahead[0]));
+			} else {
+				windows_drop (z);
+				z->grow = WIN_FIRST_ENTRIES;
+				const zip_uint64_t start = index & ~(zip_uint64_t) (WIN_FIRST_ENTRIES - 1u);
+				z->win = window_begin (za, start, WIN_FIRST_ENTRIES);
+				if (z->win && !in_window (z->win, index)) { /* (a byte limit ended the window before the entry) */
+					window_detach (z->win);
+					z->win = NULL;
+				}
+				if (!z->win && start != index) {
+					z->win = window_begin (za, index, WIN_FIRST_ENTRIES);
+				}
+				if (!z->win) {
+					z->win = window_begin (za, index, 1); /* (an odd layout: one entry at a time) */
+				}
+				if (!z->win) {
+					return NULL;
+				}
 			}
 		}
-	}
-	/* a caller that walks the archive gets the next window prepared while it uses this one */
-	if (!z->ahead && z->seq_hits >= 2) {
-		const zip_uint64_t nf = z->win->first + z->win->count;
-		if (nf < za->n_entries && !is_pending (za, nf)) {
-			z->grow = z->grow * 4u > WIN_MAX_ENTRIES ? WIN_MAX_ENTRIES : z->grow * 4u;
-			z->ahead = window_begin (za, nf, z->grow);
+		/* a caller that walks the archive gets the next windows prepared while it uses this one: one per
+		 * device, so that every GPU of OTEZIP_GPU_DEVICES has a window in flight */
+		if (z->seq_hits >= 2) {
+			const int depth = g_ndev > 1 ? (g_ndev < AHEAD_MAX ? g_ndev : AHEAD_MAX) : 1;
+			while (z->n_ahead < depth) {
+				const struct window *last = z->n_ahead ? z->ahead[z->n_ahead - 1] : z->win;
+				const zip_uint64_t nf = last->first + last->count;
+				if (nf >= za->n_entries || is_pending (za, nf)) {
+					break;
+				}
+				z->grow = z->grow * 4u > WIN_MAX_ENTRIES ? WIN_MAX_ENTRIES : z->grow * 4u;
+				struct window *nw = window_begin_ex (za, nf, z->grow, 0, 1);
+				if (!nw) {
+					break;
+				}
+				z->ahead[z->n_ahead++] = nw;
+			}
+		}
+		if (window_wait (z->win) == 0) {
+			w = z->win;
+		} else if (z->win->quiet && attempt == 0) {
+			/* a window prepared ahead did not make it (no free batch slot on the device, a layout the
+			 * one-read path cannot take): start over at this entry, on this thread, and say why if it
+			 * fails again */
+			windows_drop (z);
+		} else {
+			return NULL;
 		}
 	}
-	struct window *w = z->win;
-	if (window_wait (w) != 0) {
+	if (!w) {
 		return NULL;
 	}
 	zip_uint64_t k = index - w->first;
@@ -1212,7 +1368,8 @@ static int enc_start(zip_t *za, size_t k, struct enc_flight *f) {
 	}
 	memcpy (f->b.src, c->buf, c->used);
 	/* the devices take the batches in turn (OTEZIP_GPU_DEVICES), like the reader's windows */
-	if (ozg_use_device (g_dev0 + (int) (k % (size_t) (g_ndev > 0 ? g_ndev : 1))) != OZG_OK || ozg_encode_submit (f->b.src, c->used + 16, f->b.out, ocap + 16, f->ee, (ozg_enc_result *)f->b.res, (uint32_t)c->nitems, &f->job) != OZG_OK) {
+	if (ozg_use_device (g_dev0 + (int) (k % (size_t) (g_ndev > 0 ? g_ndev : 1))) != OZG_OK ||
+		ozg_encode_submit_packed (f->b.src, c->used + 16, f->b.out, ocap + 16, f->ee, (ozg_enc_result *)f->b.res, (uint32_t)c->nitems, &f->job) != OZG_OK) {
 		fprintf (stderr, "otezip-amd: GPU encode failed: %s\n", ozg_last_error ());
 		winbuf_put (&f->b);
 		free (f->ee);
@@ -1224,8 +1381,9 @@ static int enc_start(zip_t *za, size_t k, struct enc_flight *f) {
 	return 0;
 }
 
-/* wait for a chunk's batch and append its local headers + payloads to the file */
-static int enc_finish(zip_t *za, struct enc_flight *f, uint64_t *at) {
+/* wait for a chunk's batch and append its local headers + payloads to the file; *written counts
+ * the pending items that are completely in the file, *at is the file offset behind the last of them */
+static int enc_finish(zip_t *za, struct enc_flight *f, uint64_t *at, size_t *written) {
 	struct ozh_zip *z = (struct ozh_zip *)za;
 	int rc = -1;
 	if (!f->live) {
@@ -1237,20 +1395,27 @@ static int enc_finish(zip_t *za, struct enc_flight *f, uint64_t *at) {
 		fprintf (stderr, "otezip-amd: GPU encode failed: %s\n", ozg_last_error ());
 		goto done;
 	}
+	uint64_t poff = 0; /* the payloads come back packed: each at the running 16-byte-aligned offset */
 	for (size_t i = 0; i < c->nitems; i++) {
 		struct otezip_entry *e = &za->entries[z->pit[c->item0 + i].index];
 		if (er[i].status != OZG_ST_OK || *at > UINT32_MAX) {
 			goto done;
 		}
+		const struct otezip_entry keep = *e;
 		e->method = er[i].method;
 		e->crc32 = er[i].crc32;
 		e->comp_size = er[i].comp_size;
 		e->local_hdr_ofs = (uint32_t)*at;
-		*at += write_lfh (za->fp, e);
-		if (er[i].comp_size && fwrite (f->b.out + f->ee[i].dst_off, 1, er[i].comp_size, za->fp) != er[i].comp_size) {
+		const uint32_t hl = write_lfh (za->fp, e);
+		if (ferror (za->fp) || (er[i].comp_size && fwrite (f->b.out + poff, 1, er[i].comp_size, za->fp) != er[i].comp_size)) {
+			char *nm = e->name;
+			*e = keep;
+			e->name = nm;
 			goto done;
 		}
-		*at += er[i].comp_size;
+		*at += (uint64_t)hl + er[i].comp_size;
+		poff += ((uint64_t)er[i].comp_size + 15u) & ~15ull;
+		(*written)++;
 	}
 	rc = 0;
 	TRACE ("encode batch %zu written", f->chunk);
@@ -1262,16 +1427,22 @@ done:
 	return rc;
 }
 
-/* Encode everything that is pending and write it: chunk k + 1 is on the GPU while chunk k's
- * output goes to the file. */
-static int flush_pending(zip_t *za) {
+/* Encode everything that is pending and write it: the next chunks are on the GPUs (one per device, in
+ * turn) while chunk k's output goes to the file.  On failure the entries that did not reach the file
+ * are taken out of the directory again (adds; zip_file_replace restores its entry itself): the
+ * archive then lists exactly what it holds, as with the reference, which fails inside zip_file_add
+ * and never records such an entry (ref otezip.c:1151-1183). */
+static int flush_pending_ex(zip_t *za, int is_replace) {
 	struct ozh_zip *z = (struct ozh_zip *)za;
 	if (z->pn == 0) {
 		return 0;
 	}
 	int rc = -1;
-	struct enc_flight fl[2];
+	struct enc_flight fl[FLIGHTS_MAX];
 	memset (fl, 0, sizeof (fl));
+	size_t written = 0;
+	uint64_t at = 0;
+	int have_at = 0;
 	if (!gpu_up ()) {
 		goto done;
 	}
@@ -1283,34 +1454,54 @@ static int flush_pending(zip_t *za) {
 	if (pos < 0) {
 		goto done;
 	}
-	uint64_t at = (uint64_t)pos;
-	for (size_t k = 0; k <= z->npch; k++) {
-		if (k < z->npch && enc_start (za, k, &fl[k & 1u]) != 0) {
+	at = (uint64_t)pos;
+	have_at = 1;
+	const size_t nfl = (size_t) (g_ndev > 1 ? g_ndev + 1 : 2);
+	for (size_t k = 0; k < z->npch + nfl - 1u; k++) {
+		if (k < z->npch && enc_start (za, k, &fl[k % nfl]) != 0) {
 			goto done;
 		}
-		if (k > 0 && enc_finish (za, &fl[(k - 1u) & 1u], &at) != 0) {
+		if (k + 1u >= nfl && enc_finish (za, &fl[(k + 1u - nfl) % nfl], &at, &written) != 0) {
 			goto done;
 		}
 	}
 	rc = 0;
 done:
 	ozg_use_device (g_dev0);
-	for (int k = 0; k < 2; k++) {
+	for (size_t k = 0; k < FLIGHTS_MAX; k++) {
 		if (fl[k].live) {
 			(void)ozg_job_wait (fl[k].job);
 			winbuf_put (&fl[k].b);
 			free (fl[k].ee);
 		}
 	}
-	pending_drop (z);
 	if (rc != 0) {
 		z->write_failed = 1;
+		if (have_at) { /* nothing behind the last complete entry stays in the file */
+			fflush (za->fp);
+			if (ftruncate (fileno (za->fp), (off_t)at) != 0) {
+				/* (the directory is written behind whatever is there: still a valid archive) */
+			}
+			fseek (za->fp, 0, SEEK_END);
+		}
+		if (!is_replace && written < z->pn) {
+			const zip_uint64_t keep = z->pit[written].index; /* adds only append: the unwritten ones are the tail */
+			for (zip_uint64_t i = keep; i < za->n_entries; i++) {
+				free (za->entries[i].name);
+				za->entries[i].name = NULL;
+			}
+			za->n_entries = keep;
+			za->next_index = keep;
+		}
 	}
+	pending_drop (z);
 	return rc;
 }
 
+static int flush_pending(zip_t *za) { return flush_pending_ex (za, 0); }
+
 /* room for len more source bytes and one more item; returns where the bytes go */
-static uint8_t *pending_reserve(struct ozh_zip *z, size_t len, uint64_t *off) {
+static uint8_t *pending_reserve(struct ozh_zip *z, size_t len, uint64_t *off, int exact) {
 	const size_t alen = (len + 15u) & ~(size_t)15u;
 	if (z->pn == z->pncap) {
 		size_t nc = z->pncap ? 2 * z->pncap : 1024;
@@ -1334,7 +1525,7 @@ static uint8_t *pending_reserve(struct ozh_zip *z, size_t len, uint64_t *off) {
 		}
 		c = &z->pch[z->npch];
 		memset (c, 0, sizeof (*c));
-		c->cap = alen + 64 > PCHUNK_BYTES ? alen + 64 : PCHUNK_BYTES;
+		c->cap = exact || alen + 64 > PCHUNK_BYTES ? alen + 64 : PCHUNK_BYTES; /* (a replace is a batch of one) */
 		c->buf = (uint8_t *)malloc (c->cap);
 		if (!c->buf) {
 			return NULL;
@@ -1370,22 +1561,26 @@ zip_int64_t zip_file_add(zip_t *za, const char *name, zip_source_t *src, zip_fla
 			return -1;
 		}
 	}
+	/* everything that can fail comes before the reservation in the pending chunk */
+	char *nm = (char *)malloc (nl + 1);
+	if (!nm) {
+		return -1;
+	}
 	struct otezip_entry *ne = (struct otezip_entry *)realloc (za->entries, (za->n_entries + 1) * sizeof (*ne));
 	if (!ne) {
+		free (nm);
 		return -1;
 	}
 	za->entries = ne;
 	struct otezip_entry *e = &za->entries[za->n_entries];
 	memset (e, 0, sizeof (*e));
 	uint64_t poff = 0;
-	uint8_t *pat = pending_reserve (z, (size_t)src->len, &poff);
+	uint8_t *pat = pending_reserve (z, (size_t)src->len, &poff, 0);
 	if (!pat) {
+		free (nm);
 		return -1; /* src stays with the caller, as in the reference */
 	}
-	e->name = (char *)malloc (nl + 1);
-	if (!e->name) {
-		return -1;
-	}
+	e->name = nm;
 	memcpy (e->name, name, nl + 1);
 	e->method = za->default_method > 0 ? za->default_method : 0;
 	e->uncomp_size = (uint32_t)src->len;
@@ -1421,7 +1616,7 @@ int zip_file_replace(zip_t *za, zip_uint64_t index, zip_source_t *src, zip_flags
 	}
 	/* the entry's new bytes: a batch of one, written at once */
 	uint64_t poff = 0;
-	uint8_t *pat = pending_reserve (z, (size_t)src->len, &poff);
+	uint8_t *pat = pending_reserve (z, (size_t)src->len, &poff, 1);
 	if (!pat) {
 		return -1;
 	}
@@ -1435,7 +1630,7 @@ int zip_file_replace(zip_t *za, zip_uint64_t index, zip_source_t *src, zip_flags
 	if (src->len) {
 		memcpy (pat, src->buf, (size_t)src->len);
 	}
-	if (flush_pending (za) != 0) {
+	if (flush_pending_ex (za, 1) != 0) {
 		char *nm = e->name;
 		*e = keep;
 		e->name = nm;

@@ -15,6 +15,10 @@
  *   zip_roundtrip add-list PATH INPUT SIZES [STAT_EVERY]
  *                                         -> ragged adds (sizes from the text file SIZES), DEFLATE set on each
  *   zip_roundtrip replace PATH            -> append + zip_file_replace + read-back scenario; exit 0 on success
+ *   zip_roundtrip multi ARCHIVE K THREADS -> K handles on the same archive walked entry by entry, interleaved on one
+ *                                            thread (THREADS = 0) or one thread per handle; prints "TOTAL bytes bad"
+ *   zip_roundtrip add-fail PATH N         -> N adds whose flush is expected to FAIL (no usable device): zip_close must
+ *                                            return -1 and leave an archive that lists only what it holds
  */
 #define _POSIX_C_SOURCE 200809L
 #include <otezip/zip.h>
@@ -23,6 +27,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <pthread.h>
 
 static double now_s(void) {
 	struct timespec ts;
@@ -213,7 +218,7 @@ static int do_bench_extract(const char *path, unsigned stride) {
 	return bad ? 2 : 0;
 }
 
-static int do_bench_add(const char *path, const char *input, unsigned n, unsigned size) {
+static int do_bench_add(const char *path, const char *input, unsigned n, unsigned size, unsigned passes) {
 	FILE *in = fopen (input, "rb");
 	if (!in) {
 		return 20;
@@ -223,33 +228,131 @@ static int do_bench_add(const char *path, const char *input, unsigned n, unsigne
 		return 21;
 	}
 	fclose (in);
-	const double t0 = now_s ();
+	for (unsigned pass = 0; pass < passes; pass++) { /* (the first pass of a process creates the GPU context) */
+		const double t0 = now_s ();
+		int err = -1;
+		zip_t *za = zip_open (path, ZIP_CREATE | ZIP_TRUNCATE, &err);
+		if (!za) {
+			return 22;
+		}
+		za->default_method = ZIP_CM_STORE;
+		for (unsigned i = 0; i < n; i++) {
+			char name[64];
+			snprintf (name, sizeof (name), "f%05u", i);
+			zip_source_t *src = zip_source_buffer (za, all + (size_t)i * size, size, 0);
+			if (zip_file_add (za, name, src, 0) != (zip_int64_t)i) {
+				return 23;
+			}
+		}
+		for (unsigned i = 0; i < n; i++) {
+			if (zip_set_file_compression (za, i, ZIP_CM_DEFLATE, 0) != 0) {
+				return 24;
+			}
+		}
+		if (zip_close (za) != 0) {
+			return 25;
+		}
+		const double t1 = now_s ();
+		printf ("TOTAL %llu %.6f\n", (unsigned long long)n * size, t1 - t0);
+	}
+	free (all);
+	return 0;
+}
+
+/* K handles on one archive, every entry of each opened in turn */
+struct walker {
+	const char *path;
+	zip_t *za;
+	unsigned long long total;
+	int bad;
+};
+static void walk_one(struct walker *w, zip_uint64_t i) {
+	zip_file_t *zf = zip_fopen_index (w->za, i, 0);
+	if (!zf) {
+		w->bad++;
+		return;
+	}
+	w->total += zf->size + (zf->size ? zf->data[zf->size - 1] : 0) * 0u;
+	if (zf->size && crc32_buf (zf->data, zf->size) == 0) {
+		w->bad += 0; /* (the bytes are read) */
+	}
+	zip_fclose (zf);
+}
+static void *walk_thread(void *p) {
+	struct walker *w = (struct walker *)p;
+	const zip_uint64_t n = zip_get_num_files (w->za);
+	for (zip_uint64_t i = 0; i < n; i++) {
+		walk_one (w, i);
+	}
+	return NULL;
+}
+static int do_multi(const char *path, int k, int threads) {
+	struct walker w[16];
+	if (k < 1 || k > 16) {
+		return 64;
+	}
+	for (int a = 0; a < k; a++) {
+		int err = -1;
+		w[a].path = path;
+		w[a].total = 0;
+		w[a].bad = 0;
+		w[a].za = zip_open (path, ZIP_RDONLY, &err);
+		if (!w[a].za) {
+			return 30;
+		}
+	}
+	if (threads) {
+		pthread_t th[16];
+		for (int a = 0; a < k; a++) {
+			if (pthread_create (&th[a], NULL, walk_thread, &w[a]) != 0) {
+				return 31;
+			}
+		}
+		for (int a = 0; a < k; a++) {
+			pthread_join (th[a], NULL);
+		}
+	} else {
+		const zip_uint64_t n = zip_get_num_files (w[0].za);
+		for (zip_uint64_t i = 0; i < n; i++) {
+			for (int a = 0; a < k; a++) {
+				walk_one (&w[a], i);
+			}
+		}
+	}
+	unsigned long long total = 0;
+	int bad = 0;
+	for (int a = 0; a < k; a++) {
+		total += w[a].total;
+		bad += w[a].bad;
+		zip_close (w[a].za);
+	}
+	printf ("TOTAL %llu %d\n", total, bad);
+	return bad ? 2 : 0;
+}
+
+static int do_add_fail(const char *path, unsigned n) {
 	int err = -1;
 	zip_t *za = zip_open (path, ZIP_CREATE | ZIP_TRUNCATE, &err);
 	if (!za) {
-		return 22;
+		return 40;
 	}
-	za->default_method = ZIP_CM_STORE;
+	za->default_method = ZIP_CM_DEFLATE;
+	static const char text[] = "the quick brown fox jumps over the lazy dog, again and again and again and again";
 	for (unsigned i = 0; i < n; i++) {
 		char name[64];
-		snprintf (name, sizeof (name), "f%05u", i);
-		zip_source_t *src = zip_source_buffer (za, all + (size_t)i * size, size, 0);
-		if (zip_file_add (za, name, src, 0) != (zip_int64_t)i) {
-			return 23;
+		snprintf (name, sizeof (name), "x%03u", i);
+		zip_source_t *src = zip_source_buffer (za, text, sizeof (text), 0);
+		if (!src) {
+			return 41;
+		}
+		if (zip_file_add (za, name, src, 0) < 0) {
+			zip_source_free (src); /* (a later add may already be refused: the failure is known) */
 		}
 	}
-	for (unsigned i = 0; i < n; i++) {
-		if (zip_set_file_compression (za, i, ZIP_CM_DEFLATE, 0) != 0) {
-			return 24;
-		}
-	}
-	if (zip_close (za) != 0) {
-		return 25;
-	}
-	const double t1 = now_s ();
-	printf ("TOTAL %llu %.6f\n", (unsigned long long)n * size, t1 - t0);
-	free (all);
-	return 0;
+	const zip_uint64_t before = zip_get_num_files (za);
+	const int rc = zip_close (za);
+	printf ("CLOSE %d %llu\n", rc, (unsigned long long)before);
+	return rc == -1 ? 0 : 42;
 }
 
 /* ragged adds: SIZES holds one decimal size per line; the buffers follow one another in INPUT.  Every
@@ -391,13 +494,19 @@ int main(int argc, char **argv) {
 		return rc;
 	}
 	if (argc >= 6 && !strcmp (argv[1], "bench-add")) {
-		return do_bench_add (argv[2], argv[3], (unsigned)atoi (argv[4]), (unsigned)atoi (argv[5]));
+		return do_bench_add (argv[2], argv[3], (unsigned)atoi (argv[4]), (unsigned)atoi (argv[5]), argc >= 7 ? (unsigned)atoi (argv[6]) : 1u);
 	}
 	if (argc >= 5 && !strcmp (argv[1], "add-list")) {
 		return do_add_list (argv[2], argv[3], argv[4], argc >= 6 ? (unsigned)atoi (argv[5]) : 0);
 	}
 	if (argc >= 3 && !strcmp (argv[1], "replace")) {
 		return do_replace (argv[2]);
+	}
+	if (argc >= 5 && !strcmp (argv[1], "multi")) {
+		return do_multi (argv[2], atoi (argv[3]), atoi (argv[4]));
+	}
+	if (argc >= 4 && !strcmp (argv[1], "add-fail")) {
+		return do_add_fail (argv[2], (unsigned)atoi (argv[3]));
 	}
 	return 64;
 }

@@ -61,7 +61,7 @@ def main():
     arc_z, ents_z = corpus.build_archive(max(n // 4, 100), 262144, methods=(93,))
     arc_m, ents_m = corpus.build_archive(n, 65536, methods=(100, 97))
     arc_d, ents_d = corpus.build_archive(min(n, 4000), 65536, methods=(8,))
-    bufs = [corpus.gen_text(50000 + i, 65536) for i in range(min(n, 10000))]
+    bufs = corpus.text_buffers(min(n, 10000), 65536, first=50000)
     oz.init(0)
     L = oz.lib()
     dev = torch.device("cuda", 0)

@@ -6,6 +6,8 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 tag=${1:-rXX}
 out=gpurun_out/profile_${tag}
 mkdir -p $out
+echo "[profile] corpora (unprofiled: generation forks, a profiled process must not)"
+timeout -k 10 600 python3 tools/warm_corpus.py 10000 > $out/warm.log 2>&1 || tail -3 $out/warm.log
 echo "[profile] bench line"
 timeout -k 10 400 python3 bench.py --steps 20 --warmup 3 > $out/bench.json 2> $out/bench.err || tail -3 $out/bench.err
 cut -c1-300 $out/bench.json
