@@ -121,6 +121,13 @@ uint64_t otz_compress_data_private(uint16_t method, const uint8_t *in, uint64_t 
  * committed as fixtures (tests/golden/entries.json "ref_deflate_sizes"); the encoder is not
  * restated here. */
 
+/* Zstandard per RFC 8878 (otz_zstd_rfc.c): every frame of src (skippable frames skipped, content
+ * checksums verified).  Returns 0, -3 (corrupt / dictionary) or -5 (output does not fit);
+ * *flags bit 0: a frame carried a content checksum.  No reference code exists for this
+ * (src/lib/zstd.inc.c:172-182, :689-692); pinned against libzstd 1.4.8 of the image. */
+int otz_zstd_rfc_decode(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *out_len, uint32_t *flags);
+uint64_t otz_xxh64(const uint8_t *p, size_t n, uint64_t seed);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,6 +29,7 @@
 
 #include "otz_dispatch.h"
 #include "otz_deflate_enc.h"
+#include "otz_zstd.h"
 
 static_assert (sizeof (ozg_entry) == 32, "ozg_entry ABI");
 static_assert (sizeof (ozg_result) == 16, "ozg_result ABI");
@@ -147,8 +148,60 @@ otz_apply_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *r
 		end_bits ? end_bits + i : nullptr);
 }
 
+// Zstandard frames under method 93 (otz_zstd.h): one wavefront per entry, a persistent grid (as many
+// wavefronts as fit the chip, each taking the next entry off a counter) so that the literal scratch
+// (OTZ_ZS_LIT_BYTES per wavefront) is sized by the chip, not by the batch.  Entries that are not
+// method 93, not Zstandard candidates, out of bounds or rejected by the expansion guard are left to
+// otz_copy_kernel (route stays 0); so are payloads that turn out not to be Zstandard (route 1).
+extern "C" __global__ void __launch_bounds__ (64)
+otz_zstd_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *results, u32 n, u64 src_len, u64 dst_len, ozg_limits lim,
+	u8 *lit_scratch, u32 *cursor, u8 *route) {
+	extern __shared__ __attribute__ ((aligned (16))) u8 otz_smem[];
+	otz_zs_lds &L = *reinterpret_cast<otz_zs_lds *> (otz_smem);
+	u8 *lit = lit_scratch + (size_t)blockIdx.x * OTZ_ZS_LIT_BYTES;
+	for (;;) {
+		u32 i = 0;
+		if (otz_tid () == 0) {
+			i = atomicAdd (cursor, 1u);
+		}
+		i = otz_uniform (i);
+		if (i >= n) {
+			break;
+		}
+		const ozg_entry e = entries[i];
+		u32 take = e.method == OZG_METHOD_ZSTD && otz_entry_in_bounds (e, src_len, dst_len) && !otz_zipbomb (e, lim) &&
+			otz_zs_is_candidate (src + e.src_off, e.comp_size) ? 1u : 0u;
+		if (otz_uniform (take) == 0u) { // (the same in every lane; saying so keeps the loop's control flow uniform)
+			continue;
+		}
+		otz_zs_run (L, src + e.src_off, e.comp_size, dst + e.dst_off, e.uncomp_size, lit, &results[i], &route[i]);
+		otz_wave_sync ();
+	}
+}
+
+// CRC-32 of the entries otz_zstd_kernel decoded (ref src/lib/otezip.c:667-679)
 extern "C" __global__ void __launch_bounds__ (256)
-otz_copy_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *results, u32 n, u64 src_len, u64 dst_len, ozg_limits lim) {
+otz_zstd_crc_kernel(u8 *dst, const ozg_entry *entries, ozg_result *results, u32 n, const u8 *route) {
+	extern __shared__ __attribute__ ((aligned (16))) u8 otz_smem[];
+	const u32 i = blockIdx.x;
+	if (i >= n || route[i] != OTZ_ZS_ROUTE_DONE || results[i].status != OZG_ST_OK) {
+		return;
+	}
+	otz_copy_lds &L = *reinterpret_cast<otz_copy_lds *> (otz_smem);
+	otz_crc_load_slice4 (L.t4);
+	otz_crc_load_adv4k (L.a4);
+	otz_sync ();
+	const u32 m = results[i].total_out;
+	const u32 R = otz_stream_crc (L, dst + entries[i].dst_off, nullptr, m, false);
+	if (otz_tid () == 0) {
+		const u32 crc = ~(otz_gf_mul (0xFFFFFFFFu, otz_xpow_bytes (m)) ^ R);
+		results[i].crc32 = crc;
+		results[i].flags = crc != entries[i].crc32 ? OZG_F_CRC_MISMATCH : 0u;
+	}
+}
+
+extern "C" __global__ void __launch_bounds__ (256)
+otz_copy_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *results, u32 n, u64 src_len, u64 dst_len, ozg_limits lim, const u8 *route) {
 	extern __shared__ __attribute__ ((aligned (16))) u8 otz_smem[];
 	u32 i = blockIdx.x;
 	if (i >= n) {
@@ -158,6 +211,9 @@ otz_copy_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *re
 	ozg_entry e = entries[i];
 	if (e.method == OZG_METHOD_DEFLATE) {
 		return;
+	}
+	if (route && route[i] == OTZ_ZS_ROUTE_DONE) {
+		return; // a Zstandard frame: otz_zstd_kernel has decoded it
 	}
 	if (!otz_entry_in_bounds (e, src_len, dst_len)) {
 		otz_fail (&results[i], OZG_ST_INTERNAL);
@@ -389,6 +445,12 @@ struct workspace {
 	bool busy = false;
 	hipStream_t aux[2] = { nullptr, nullptr };
 	hipEvent_t fork = nullptr, join[2] = { nullptr, nullptr };
+	// Zstandard: literal scratch of the persistent grid, its entry counter, the routing bytes
+	u8 *zs_lit = nullptr;
+	u32 zs_grid = 0;
+	u32 *zs_cursor = nullptr;
+	u8 *zs_route = nullptr;
+	size_t zs_route_cap = 0;
 	// encode side: token scratch of the persistent grid, its buffer counter
 	u32 *enc_tok = nullptr;
 	u32 enc_grid = 0;
@@ -422,6 +484,7 @@ struct dev_ctx {
 	bool ready = false;
 	u32 gen = 4096; // index wavefronts resident on the chip at once
 	u32 enc_grid = 2048; // encode wavefronts resident on the chip at once (LDS-bound)
+	u32 zs_grid = 3840;  // Zstandard wavefronts resident on the chip at once
 	staging stage; // synchronous host entry points
 	workspace ws;
 	ozg_job slots[N_SLOTS];
@@ -547,6 +610,9 @@ void ws_free(workspace &ws) {
 	(void)hipFree (ws.ovf);
 	(void)hipFree (ws.enc_tok);
 	(void)hipFree (ws.enc_cursor);
+	(void)hipFree (ws.zs_lit);
+	(void)hipFree (ws.zs_cursor);
+	(void)hipFree (ws.zs_route);
 	if (ws.enc_done) {
 		(void)hipEventDestroy (ws.enc_done);
 	}
@@ -562,6 +628,8 @@ void ws_free(workspace &ws) {
 	}
 	ws = workspace ();
 }
+
+hipEvent_t ws_done_event(dev_ctx &C) { return C.ws.done; }
 
 // the launches of one decode batch on stream s (device pointers); the caller holds g_mu
 int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, uint64_t dst_len, const ozg_entry *d_entries,
@@ -627,16 +695,64 @@ int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, 
 		ws.busy = true;
 	}
 	if (!(batch_flags & OZG_BATCH_ONLY_DEFLATE)) {
+		const u8 *route = nullptr;
+		if (!(batch_flags & OZG_BATCH_NO_ZSTD)) {
+			// method 93: Zstandard frames first (the rest of the batch, and what turns out not to be
+			// Zstandard, is the copy kernel's)
+			workspace &ws = C.ws;
+			const u32 grid = n < C.zs_grid ? n : C.zs_grid;
+			if (!ws.done) {
+				OZG_HIP (hipEventCreateWithFlags (&ws.done, hipEventDisableTiming));
+			}
+			if (!ws.zs_cursor) {
+				OZG_HIP (hipMalloc ((void **)&ws.zs_cursor, 256));
+			}
+			if (grid > ws.zs_grid || n > ws.zs_route_cap) {
+				OZG_HIP (hipDeviceSynchronize ()); // an earlier batch may still use what is about to be freed
+				ws.busy = false;
+			}
+			if (grid > ws.zs_grid) {
+				(void)hipFree (ws.zs_lit);
+				ws.zs_lit = nullptr;
+				ws.zs_grid = 0;
+				const u32 g = grid < 64u ? 64u : (grid + (grid >> 1) < C.zs_grid ? grid + (grid >> 1) : C.zs_grid);
+				OZG_HIP (hipMalloc ((void **)&ws.zs_lit, (size_t)g * OTZ_ZS_LIT_BYTES));
+				ws.zs_grid = g;
+			}
+			if (n > ws.zs_route_cap) {
+				(void)hipFree (ws.zs_route);
+				ws.zs_route = nullptr;
+				ws.zs_route_cap = 0;
+				const size_t cap = n < 1024u ? 1024u : n + (n >> 2);
+				OZG_HIP (hipMalloc ((void **)&ws.zs_route, cap));
+				ws.zs_route_cap = cap;
+			}
+			if (ws.busy) {
+				OZG_HIP (hipStreamWaitEvent (s, ws.done, 0)); // the scratch is shared between streams
+			}
+			OZG_HIP (hipMemsetAsync (ws.zs_cursor, 0, 4, s));
+			OZG_HIP (hipMemsetAsync (ws.zs_route, 0, n, s));
+			hipLaunchKernelGGL (otz_zstd_kernel, dim3 (grid), dim3 (64), sizeof (otz_zs_lds), s, (const u8 *)d_src, (u8 *)d_dst, d_entries, d_results, n,
+				(u64)src_len, (u64)dst_len, g_limits, ws.zs_lit, ws.zs_cursor, ws.zs_route);
+			OZG_HIP (hipGetLastError ());
+			route = ws.zs_route;
+		}
 		hipLaunchKernelGGL (otz_copy_kernel, dim3 (n), dim3 (256), sizeof (otz_copy_lds), s, (const u8 *)d_src,
-			(u8 *)d_dst, d_entries, d_results, n, (u64)src_len, (u64)dst_len, g_limits);
+			(u8 *)d_dst, d_entries, d_results, n, (u64)src_len, (u64)dst_len, g_limits, route);
 		OZG_HIP (hipGetLastError ());
+		if (route) {
+			hipLaunchKernelGGL (otz_zstd_crc_kernel, dim3 (n), dim3 (256), sizeof (otz_copy_lds), s, (u8 *)d_dst, d_entries, d_results, n, route);
+			OZG_HIP (hipGetLastError ());
+			OZG_HIP (hipEventRecord (ws_done_event (C), s));
+			C.ws.busy = true;
+		}
 	}
 	return OZG_OK;
 }
 
 // host-side view of a descriptor table: bounds, and which launches it needs
 int check_entries(const ozg_entry *entries, uint32_t n, uint64_t src_len, uint64_t dst_len, uint32_t *flags) {
-	uint32_t f = OZG_BATCH_NO_DEFLATE | OZG_BATCH_ONLY_DEFLATE;
+	uint32_t f = OZG_BATCH_NO_DEFLATE | OZG_BATCH_ONLY_DEFLATE | OZG_BATCH_NO_ZSTD;
 	for (uint32_t i = 0; i < n; i++) {
 		const ozg_entry &e = entries[i];
 		if (e.src_off > src_len || e.comp_size > src_len - e.src_off || (e.dst_off & 15u) || e.dst_off > dst_len ||
@@ -645,6 +761,9 @@ int check_entries(const ozg_entry *entries, uint32_t n, uint64_t src_len, uint64
 			return OZG_E_ARG;
 		}
 		f &= e.method == OZG_METHOD_DEFLATE ? ~OZG_BATCH_NO_DEFLATE : ~OZG_BATCH_ONLY_DEFLATE;
+		if (e.method == OZG_METHOD_ZSTD) {
+			f &= ~OZG_BATCH_NO_ZSTD;
+		}
 	}
 	*flags = f;
 	return OZG_OK;
@@ -709,6 +828,8 @@ int ozg_init(int device) {
 			(int)sizeof (otz_enc_lds)));
 		OZG_HIP (hipFuncSetAttribute ((const void *)otz_encode_prof_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
 			(int)sizeof (otz_enc_lds)));
+		OZG_HIP (hipFuncSetAttribute ((const void *)otz_zstd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof (otz_zs_lds)));
+		OZG_HIP (hipFuncSetAttribute ((const void *)otz_zstd_crc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof (otz_copy_lds)));
 		int cus = 256, per_cu = 16;
 		(void)hipDeviceGetAttribute (&cus, hipDeviceAttributeMultiprocessorCount, phys_of (device));
 		(void)hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu, otz_index_kernel, 64, sizeof (otz_k1_lds));
@@ -716,6 +837,9 @@ int ozg_init(int device) {
 		per_cu = 8;
 		(void)hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu, otz_encode_kernel, 64, sizeof (otz_enc_lds));
 		g_dev[device].enc_grid = (u32) (cus > 0 ? cus : 256) * (u32) (per_cu > 0 ? per_cu : 8);
+		per_cu = 12;
+		(void)hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu, otz_zstd_kernel, 64, sizeof (otz_zs_lds));
+		g_dev[device].zs_grid = (u32) (cus > 0 ? cus : 256) * (u32) (per_cu > 0 ? per_cu : 12);
 		g_dev[device].ready = true;
 	}
 	if (const char *c = getenv ("OTEZIP_GPU_CHUNKS")) {

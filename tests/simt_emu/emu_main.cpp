@@ -6,6 +6,7 @@
 #include "otz_deflate_enc.h"
 #include "otz_huff_index.h"
 #include "otz_lz_apply.h"
+#include "otz_zstd.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -49,6 +50,8 @@ struct block_args {
 	const ozg_enc_entry *enc_e; // phase 3: encode kernel body
 	ozg_enc_result *enc_r;
 	u32 *enc_tok;
+	u8 *zs_lit;   // phase 4: Zstandard wavefront body; phase 5: its CRC pass
+	u8 *zs_route;
 };
 
 void *thread_main(void *p) {
@@ -57,6 +60,25 @@ void *thread_main(void *p) {
 	otz_emu_self.blk = a->blk;
 	if (a->phase == 3) {
 		otz_encode_entry<false> (*(otz_enc_lds *)a->lds, a->src, a->dst, *a->enc_e, a->enc_r, a->enc_tok);
+	} else if (a->phase == 4) {
+		// what otz_zstd_kernel does for one entry
+		const ozg_entry &e = *a->e;
+		if (!otz_zipbomb (e, a->lim) && otz_zs_is_candidate (a->src + e.src_off, e.comp_size)) {
+			otz_zs_run (*(otz_zs_lds *)a->lds, a->src + e.src_off, e.comp_size, a->dst + e.dst_off, e.uncomp_size, a->zs_lit, a->r, a->zs_route);
+		}
+	} else if (a->phase == 5) {
+		// what otz_zstd_crc_kernel does
+		otz_copy_lds &L = *(otz_copy_lds *)a->lds;
+		otz_crc_load_slice4 (L.t4);
+		otz_crc_load_adv4k (L.a4);
+		otz_sync ();
+		const u32 m = a->r->total_out;
+		const u32 R = otz_stream_crc (L, a->dst + a->e->dst_off, nullptr, m, false);
+		if (otz_tid () == 0) {
+			const u32 crc = ~(otz_gf_mul (0xFFFFFFFFu, otz_xpow_bytes (m)) ^ R);
+			a->r->crc32 = crc;
+			a->r->flags = crc != a->e->crc32 ? OZG_F_CRC_MISMATCH : 0u;
+		}
 	} else if (a->phase == 1) {
 		otz_run_index<false> (*(otz_k1_lds *)a->lds, a->src, a->dst, *a->e, a->lim, a->head, a->region, a->region_bytes);
 	} else if (a->phase == 2) {
@@ -221,6 +243,23 @@ extern "C" int emu_decode_batch_mode(const void *src, uint64_t src_len, void *ds
 		a.e = &entries[i];
 		a.r = &results[i];
 		a.lim = { ratio, slack };
+		if (entries[i].method == OZG_METHOD_ZSTD) {
+			// product order: Zstandard kernel, copy kernel (private framing) unless it decoded the entry, CRC pass
+			std::vector<u8> lit (OTZ_ZS_LIT_BYTES, 0xA5);
+			u8 route = OTZ_ZS_ROUTE_NONE;
+			a.zs_lit = lit.data ();
+			a.zs_route = &route;
+			a.phase = 4;
+			run_block (64, a, sizeof (otz_zs_lds));
+			a.phase = 0;
+			if (route != OTZ_ZS_ROUTE_DONE) {
+				run_block (OTZ_CNT, a, lds_bytes);
+			} else if (results[i].status == OZG_ST_OK) {
+				a.phase = 5;
+				run_block (OTZ_CNT, a, lds_bytes);
+			}
+			continue;
+		}
 		if (entries[i].method != OZG_METHOD_DEFLATE) {
 			run_block (OTZ_CNT, a, lds_bytes);
 			continue;
@@ -258,6 +297,7 @@ extern "C" int emu_decode_batch(const void *src, uint64_t src_len, void *dst, ui
 extern "C" uint32_t emu_lds_bytes_index(void) { return (uint32_t)sizeof (otz_k1_lds); }
 extern "C" uint32_t emu_lds_bytes_inflate(void) { return (uint32_t)sizeof (otz_inflate_lds); }
 extern "C" uint32_t emu_lds_bytes_copy(void) { return (uint32_t)sizeof (otz_copy_lds); }
+extern "C" uint32_t emu_lds_bytes_zstd(void) { return (uint32_t)sizeof (otz_zs_lds); }
 
 // ---- encode side: one 64-thread workgroup per buffer (CRC is left to the caller in emulation)
 extern "C" int emu_encode_batch(const void *src, void *dst, const ozg_enc_entry *entries, ozg_enc_result *results, uint32_t n) {
