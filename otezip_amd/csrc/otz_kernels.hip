@@ -42,6 +42,9 @@ static_assert (sizeof (otz_ix_head) == 32 && sizeof (otz_ix_block) == 32 && size
 #ifndef OTZ_K1_WPE
 #define OTZ_K1_WPE 4
 #endif
+#ifndef OTZ_ZS_WPE
+#define OTZ_ZS_WPE 4 // the Zstandard kernel's LDS (10.6 KB) admits 15 wavefronts per CU: registers must not halve that
+#endif
 
 // the encode-side descriptor check (overflow-safe), cf. otz_entry_in_bounds
 OTZ_DEV bool otz_enc_entry_in_bounds(const ozg_enc_entry &e, u64 src_len, u64 dst_len) {
@@ -153,9 +156,9 @@ otz_apply_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *r
 // (OTZ_ZS_LIT_BYTES per wavefront) is sized by the chip, not by the batch.  Entries that are not
 // method 93, not Zstandard candidates, out of bounds or rejected by the expansion guard are left to
 // otz_copy_kernel (route stays 0); so are payloads that turn out not to be Zstandard (route 1).
-extern "C" __global__ void __launch_bounds__ (64)
-otz_zstd_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *results, u32 n, u64 src_len, u64 dst_len, ozg_limits lim,
-	u8 *lit_scratch, u32 *cursor, u8 *route) {
+template <bool PROF>
+__device__ __forceinline__ void otz_zstd_grid(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *results, u32 n, u64 src_len, u64 dst_len, ozg_limits lim,
+	u8 *lit_scratch, u32 *cursor, u8 *route, u64 *prof) {
 	extern __shared__ __attribute__ ((aligned (16))) u8 otz_smem[];
 	otz_zs_lds &L = *reinterpret_cast<otz_zs_lds *> (otz_smem);
 	u8 *lit = lit_scratch + (size_t)blockIdx.x * OTZ_ZS_LIT_BYTES;
@@ -174,9 +177,22 @@ otz_zstd_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *re
 		if (otz_uniform (take) == 0u) { // (the same in every lane; saying so keeps the loop's control flow uniform)
 			continue;
 		}
-		otz_zs_run (L, src + e.src_off, e.comp_size, dst + e.dst_off, e.uncomp_size, lit, &results[i], &route[i]);
+		otz_zs_run<PROF> (L, src + e.src_off, e.comp_size, dst + e.dst_off, e.uncomp_size, lit, &results[i], &route[i], PROF && prof ? prof + 32ull * i : nullptr);
 		otz_wave_sync ();
 	}
+}
+
+extern "C" __global__ void __launch_bounds__ (64) __attribute__ ((amdgpu_waves_per_eu (OTZ_ZS_WPE, 8)))
+otz_zstd_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *results, u32 n, u64 src_len, u64 dst_len, ozg_limits lim,
+	u8 *lit_scratch, u32 *cursor, u8 *route) {
+	otz_zstd_grid<false> (src, dst, entries, results, n, src_len, dst_len, lim, lit_scratch, cursor, route, nullptr);
+}
+
+// diagnostic build with per-phase cycle counters (tools/prof_zstd.py)
+extern "C" __global__ void __launch_bounds__ (64)
+otz_zstd_prof_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *results, u32 n, u64 src_len, u64 dst_len, ozg_limits lim,
+	u8 *lit_scratch, u32 *cursor, u8 *route, u64 *prof) {
+	otz_zstd_grid<true> (src, dst, entries, results, n, src_len, dst_len, lim, lit_scratch, cursor, route, prof);
 }
 
 // CRC-32 of the entries otz_zstd_kernel decoded (ref src/lib/otezip.c:667-679)
@@ -732,8 +748,13 @@ int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, 
 			}
 			OZG_HIP (hipMemsetAsync (ws.zs_cursor, 0, 4, s));
 			OZG_HIP (hipMemsetAsync (ws.zs_route, 0, n, s));
-			hipLaunchKernelGGL (otz_zstd_kernel, dim3 (grid), dim3 (64), sizeof (otz_zs_lds), s, (const u8 *)d_src, (u8 *)d_dst, d_entries, d_results, n,
-				(u64)src_len, (u64)dst_len, g_limits, ws.zs_lit, ws.zs_cursor, ws.zs_route);
+			if (g_prof) {
+				hipLaunchKernelGGL (otz_zstd_prof_kernel, dim3 (grid), dim3 (64), sizeof (otz_zs_lds), s, (const u8 *)d_src, (u8 *)d_dst, d_entries, d_results, n,
+					(u64)src_len, (u64)dst_len, g_limits, ws.zs_lit, ws.zs_cursor, ws.zs_route, g_prof);
+			} else {
+				hipLaunchKernelGGL (otz_zstd_kernel, dim3 (grid), dim3 (64), sizeof (otz_zs_lds), s, (const u8 *)d_src, (u8 *)d_dst, d_entries, d_results, n,
+					(u64)src_len, (u64)dst_len, g_limits, ws.zs_lit, ws.zs_cursor, ws.zs_route);
+			}
 			OZG_HIP (hipGetLastError ());
 			route = ws.zs_route;
 		}
@@ -829,6 +850,7 @@ int ozg_init(int device) {
 		OZG_HIP (hipFuncSetAttribute ((const void *)otz_encode_prof_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
 			(int)sizeof (otz_enc_lds)));
 		OZG_HIP (hipFuncSetAttribute ((const void *)otz_zstd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof (otz_zs_lds)));
+		OZG_HIP (hipFuncSetAttribute ((const void *)otz_zstd_prof_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof (otz_zs_lds)));
 		OZG_HIP (hipFuncSetAttribute ((const void *)otz_zstd_crc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof (otz_copy_lds)));
 		int cus = 256, per_cu = 16;
 		(void)hipDeviceGetAttribute (&cus, hipDeviceAttributeMultiprocessorCount, phys_of (device));

@@ -38,6 +38,7 @@
 #define OTZ_ZS_BLOCK_MAX (128u * 1024u)
 #define OTZ_ZS_LIT_BYTES (OTZ_ZS_BLOCK_MAX + 64u) // literal buffer per wavefront (global memory)
 #define OTZ_ZS_HUF_LOG_MAX 11u
+#define OTZ_ZS_SBUF 1024u // staged bytes of the sequence bitstream: a group of 64 sequences reads at most 64 x 105 bits = 840 bytes
 // route[] values (one byte per entry of the batch, zeroed per batch)
 #define OTZ_ZS_ROUTE_NONE 0u
 #define OTZ_ZS_ROUTE_PRIVATE 1u // not a Zstandard frame after all: otz_copy_kernel decodes the private framing
@@ -49,9 +50,7 @@ typedef int64_t i64;
 struct otz_zs_lds {
 	u16 huf[1u << OTZ_ZS_HUF_LOG_MAX]; // literal code: symbol | bits << 8
 	u32 fse_ll[512], fse_ml[512], fse_of[256]; // symbol | state bits << 8 | baseline << 16
-	u32 ll_base[36], ml_base[53];
-	u8 ll_bits[36], ml_bits[53];
-	u8 pad0[3];
+	u32 ll_tab[36], ml_tab[53]; // baseline | extra bits << 24 of the literal-length / match-length codes
 	union {
 		struct { // a group of sequences and the prefix arrays of its flattened copies
 			u32 g_ll[64], g_ml[64], g_off[64];
@@ -66,6 +65,8 @@ struct otz_zs_lds {
 			u32 wtab[64]; // FSE table of the Huffman weights (accuracy <= 6)
 		} b;
 	};
+	u8 sbuf[OTZ_ZS_SBUF + 32u]; // the stretch of the sequence bitstream lane 0 is reading (staged by all lanes):
+	                            // stream byte k sits at sbuf[16 + k - wlo]
 	u32 huf_log;     // 0: no literal code yet (treeless blocks need one)
 	u32 ll_log, ml_log, of_log;
 	u32 have_ll, have_ml, have_of;
@@ -104,6 +105,31 @@ OTZ_DEV void otz_zs_reload(otz_zs_bits &b) {
 	b.cbit = lo * 8;
 	b.c = otz_zs_ld64 (b.p, (u32)lo, b.n);
 }
+
+// The sequence bitstream's reader (lane 0): the same stream, read from the LDS window the wavefront
+// stages, with libzstd's container discipline -- c holds the stream bytes [ptr, ptr + 8), `used` bits of
+// it (from the top) are consumed; a read is two shifts, a reload (at fixed points of a sequence, so the
+// loop is straight-line code) moves ptr down by the whole bytes consumed.
+struct otz_zs_sbits {
+	const u8 *w; // L.sbuf
+	i32 wlo;     // stream byte at w[16]
+	i32 ptr;
+	u64 c;
+	u32 used;
+};
+OTZ_DEV void otz_zs_sreload(otz_zs_sbits &b) {
+	b.ptr -= (i32) (b.used >> 3);
+	b.used &= 7u;
+	i32 at = 16 + b.ptr - b.wlo;
+	at = at < 0 ? 0 : at; // (only a corrupt stream gets here: its position goes negative and the group is rejected)
+	b.c = otz_ld64u (b.w + at);
+}
+OTZ_DEV u32 otz_zs_sread(otz_zs_sbits &b, u32 nb) { // nb <= 32
+	const u32 v = (u32) (((b.c << b.used) >> 1) >> (63u - nb));
+	b.used += nb;
+	return v;
+}
+OTZ_DEV i32 otz_zs_spos(const otz_zs_sbits &b) { return 8 * b.ptr + 64 - (i32)b.used; } // unread bits; negative: over-read
 OTZ_DEV bool otz_zs_bits_init(otz_zs_bits &b, const u8 *p, u32 n) {
 	b.p = p;
 	b.n = n;
@@ -135,6 +161,9 @@ OTZ_DEV u32 otz_zs_read(otz_zs_bits &b, u32 nb) {
 }
 // peek nb (<= 16) bits without consuming; bits beyond the start read as zero
 OTZ_DEV u32 otz_zs_peek(otz_zs_bits &b, u32 nb) {
+	if (b.bit <= 0) {
+		return 0;
+	}
 	i32 lo = b.bit - (i32)nb;
 	u32 sh = 0;
 	if (lo < 0) {
@@ -163,7 +192,7 @@ OTZ_DEV u32 otz_zs_fpeek(const u8 *p, u32 n, u32 bit, u32 nb) {
 }
 
 // normalized counts (RFC 8878 4.1.1) into L.b.norm; returns bytes used or 0 on error
-OTZ_DEV u32 otz_zs_read_norm(otz_zs_lds &L, const u8 *p, u32 n, u32 *nsym, u32 *log, u32 max_log, u32 max_sym) {
+OTZ_DEV_NOINLINE u32 otz_zs_read_norm(otz_zs_lds &L, const u8 *p, u32 n, u32 *nsym, u32 *log, u32 max_log, u32 max_sym) {
 	if (n == 0) {
 		return 0;
 	}
@@ -224,7 +253,7 @@ OTZ_DEV u32 otz_zs_read_norm(otz_zs_lds &L, const u8 *p, u32 n, u32 *nsym, u32 *
 }
 
 // decoding table from L.b.norm[0..nsym) (RFC 8878 4.1.1); false on an inconsistent distribution
-OTZ_DEV bool otz_zs_fse_build(otz_zs_lds &L, u32 *tab, u32 nsym, u32 log) {
+OTZ_DEV_NOINLINE bool otz_zs_fse_build(otz_zs_lds &L, u32 *tab, u32 nsym, u32 log) {
 	const u32 size = 1u << log;
 	i32 high = (i32)size - 1;
 	for (u32 s = 0; s < nsym; s++) {
@@ -274,7 +303,7 @@ OTZ_CONST_TABLE u8 otz_zs_ml_bits_c[53] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 
 	7, 8, 9, 10, 11, 12, 13, 14, 15, 16 };
 
 // one of the three sequence tables (lane 0); returns bytes used, or 0xFFFFFFFF on error
-OTZ_DEV u32 otz_zs_seq_table(otz_zs_lds &L, u32 *tab, u32 *log, u32 *have, u32 mode, const u8 *p, u32 n, const int8_t *def, u32 def_n, u32 def_log,
+OTZ_DEV_NOINLINE u32 otz_zs_seq_table(otz_zs_lds &L, u32 *tab, u32 *log, u32 *have, u32 mode, const u8 *p, u32 n, const int8_t *def, u32 def_n, u32 def_log,
 	u32 max_log, u32 max_sym) {
 	if (mode == 0) {
 		for (u32 s = 0; s < def_n; s++) {
@@ -312,7 +341,7 @@ OTZ_DEV u32 otz_zs_seq_table(otz_zs_lds &L, u32 *tab, u32 *log, u32 *have, u32 m
 // ---------------------------------------------------------------- Huffman literals
 
 // Huffman tree description (RFC 8878 4.2.1) -> L.huf (lane 0); returns bytes used or 0 on error
-OTZ_DEV u32 otz_zs_read_tree(otz_zs_lds &L, const u8 *p, u32 n) {
+OTZ_DEV_NOINLINE u32 otz_zs_read_tree(otz_zs_lds &L, const u8 *p, u32 n) {
 	if (n == 0) {
 		return 0;
 	}
@@ -434,7 +463,21 @@ OTZ_DEV bool otz_zs_huf_stream(const otz_zs_lds &L, const u8 *p, u32 n, u8 *out,
 		return false;
 	}
 	const u32 hl = L.huf_log;
-	for (u32 i = 0; i < nout; i++) {
+	u32 i = 0;
+	for (; i + 8u <= nout; i += 8u) { // eight literals per (unaligned) 8-byte store
+		u64 acc = 0;
+#pragma unroll
+		for (u32 k = 0; k < 8u; k++) {
+			const u32 e = L.huf[otz_zs_peek (b, hl)];
+			acc |= (u64) (e & 0xFFu) << (8u * k);
+			b.bit -= (i32) (e >> 8);
+		}
+		if (b.bit < 0) {
+			return false;
+		}
+		otz_st64u (out + i, acc);
+	}
+	for (; i < nout; i++) {
 		const u32 e = L.huf[otz_zs_peek (b, hl)];
 		out[i] = (u8)e;
 		b.bit -= (i32) (e >> 8);
@@ -458,9 +501,29 @@ OTZ_DEV u32 otz_zs_find(const u32 *pre, u32 f) {
 	return s;
 }
 
+// One flattened copy of the matches of the lanes in `sel` (their lengths in L.g.g_ml, offsets in L.g.g_off).
+OTZ_DEV void otz_zs_copy_matches(otz_zs_lds &L, bool sel, u32 ml, u32 mstart, u8 *out) {
+	const u32 lane = otz_lane ();
+	const u32 rml = sel ? ml : 0u;
+	const u32 incl = otz_wave_scan_incl (rml);
+	const u32 tot_r = otz_readlane (incl, 63u);
+	otz_wave_sync_lds ();
+	L.g.pre_a[lane] = incl - rml;
+	L.g.pre_b[lane] = mstart;
+	otz_wave_sync_lds ();
+	for (u32 f = lane; f < tot_r; f += 64u) {
+		const u32 s = otz_zs_find (L.g.pre_a, f);
+		const u32 k = f - L.g.pre_a[s], o = L.g.g_off[s], ms = L.g.pre_b[s];
+		const u32 src = o >= L.g.g_ml[s] ? ms + k - o : ms - o + k % o; // an overlapping match repeats its first `o` bytes
+		out[ms + k] = out[src];
+	}
+}
+
 // All 64 lanes.  ng (1..64) sequences in L.g.*; literals from lit[*lpos ...), output at out[*opos ...).
-// frame_start: offsets may not reach in front of it.  Returns 0, OZG_ST_DATA or OZG_ST_SIZE.
-OTZ_DEV int otz_zs_execute(otz_zs_lds &L, u32 ng, u8 *out, u32 cap, u32 *opos, const u8 *lit, u32 nlit, u32 *lpos, u32 frame_start) {
+// frame_start: offsets may not reach in front of it.  *synced: every output byte below this position is
+// known to be in memory (a fence has run since it was stored): a match whose source lies below it can be
+// copied without one.  Returns 0, OZG_ST_DATA or OZG_ST_SIZE.
+OTZ_DEV int otz_zs_execute(otz_zs_lds &L, u32 ng, u8 *out, u32 cap, u32 *opos, const u8 *lit, u32 nlit, u32 *lpos, u32 frame_start, u32 *synced) {
 	const u32 lane = otz_lane ();
 	const bool mine = lane < ng;
 	const u32 ll = mine ? L.g.g_ll[lane] : 0u, ml = mine ? L.g.g_ml[lane] : 0u, off = mine ? L.g.g_off[lane] : 1u;
@@ -487,32 +550,25 @@ OTZ_DEV int otz_zs_execute(otz_zs_lds &L, u32 ng, u8 *out, u32 cap, u32 *opos, c
 		const u32 s = otz_zs_find (L.g.pre_a, f);
 		out[L.g.pre_b[s] + (f - L.g.pre_a[s])] = lit[*lpos + f];
 	}
-	otz_wave_sync (); // the literal bytes are in memory before a match reads them
-	// ---- matches, in rounds: a match is ready once everything its source needs is final
+	// ---- matches whose source is already in memory: no fence needed (most of them: offsets are long)
 	bool done = !mine || ml == 0;
 	const u32 span = ml < off ? ml : off;
 	const u32 src_hi = mstart - off + span;
-	for (;;) {
+	{
+		const bool far = !done && src_hi <= *synced;
+		if (otz_ballot (far) != 0) {
+			otz_zs_copy_matches (L, far, ml, mstart, out);
+			done = done || far;
+		}
+	}
+	// ---- the others in rounds: a match is ready once everything its source needs is final and in memory
+	while (otz_ballot (!done) != 0) {
+		otz_wave_sync (); // what has been stored so far is in memory now
 		const u64 pend = otz_ballot (!done);
-		if (pend == 0) {
-			break;
-		}
 		const u32 F = otz_readlane (mstart, otz_ctz64 (pend)); // start of the first unfinished match
+		*synced = F;
 		const bool ready = !done && src_hi <= F;
-		const u32 rml = ready ? ml : 0u;
-		const u32 incl = otz_wave_scan_incl (rml);
-		const u32 tot_r = otz_readlane (incl, 63u);
-		otz_wave_sync_lds ();
-		L.g.pre_a[lane] = incl - rml;
-		L.g.pre_b[lane] = mstart;
-		otz_wave_sync_lds ();
-		for (u32 f = lane; f < tot_r; f += 64u) {
-			const u32 s = otz_zs_find (L.g.pre_a, f);
-			const u32 k = f - L.g.pre_a[s], o = L.g.g_off[s], ms = L.g.pre_b[s];
-			const u32 src = o >= L.g.g_ml[s] ? ms + k - o : ms - o + k % o; // an overlapping match repeats its first `o` bytes
-			out[ms + k] = out[src];
-		}
-		otz_wave_sync ();
+		otz_zs_copy_matches (L, ready, ml, mstart, out);
 		done = done || ready;
 	}
 	*opos += tot;
@@ -543,7 +599,7 @@ OTZ_DEV u64 otz_rotl64(u64 x, u32 r) { return (x << r) | (x >> (64u - r)); }
 OTZ_DEV u64 otz_xround(u64 acc, u64 in) { return otz_rotl64 (acc + in * OTZ_XP2, 31) * OTZ_XP1; }
 OTZ_DEV u64 otz_xmerge(u64 h, u64 v) { return (h ^ otz_xround (0, v)) * OTZ_XP1 + OTZ_XP4; }
 // all lanes call; lanes 0-3 run the four accumulators, every lane gets the digest
-OTZ_DEV u64 otz_zs_xxh64(const u8 *p, u32 n) {
+OTZ_DEV_NOINLINE u64 otz_zs_xxh64(const u8 *p, u32 n) {
 	const u32 lane = otz_lane ();
 	const u32 stripes = n >> 5;
 	u64 v = lane == 0 ? OTZ_XP1 + OTZ_XP2 : lane == 1u ? OTZ_XP2 : lane == 2u ? 0ull : 0ull - OTZ_XP1;
@@ -598,7 +654,18 @@ OTZ_DEV u64 otz_zs_xxh64(const u8 *p, u32 n) {
 OTZ_DEV u32 otz_zs_bcast(u32 v) { return otz_readlane (v, 0); }
 
 // One compressed block.  All lanes.  p/n: the block's bytes.  Returns 0 or a status.
-OTZ_DEV int otz_zs_block(otz_zs_lds &L, const u8 *p, u32 n, u8 *out, u32 cap, u32 *opos, u8 *lit, u32 frame_start, u32 rep[3]) {
+// pc (PROF builds): cycles of 0 literals, 1 sequence tables, 2 sequence decoding (lane 0), 3 sequence execution, 4 bitstream staging
+#define OTZ_ZS_MARK(i) \
+	do { \
+		if (PROF) { \
+			const u64 _t = otz_cycles (); \
+			pc[i] += _t - plast; \
+			plast = _t; \
+		} \
+	} while (0)
+template <bool PROF>
+OTZ_DEV int otz_zs_block(otz_zs_lds &L, const u8 *p, u32 n, u8 *out, u32 cap, u32 *opos, u8 *lit, u32 frame_start, u32 rep[3], u32 *synced, u64 *pc) {
+	u64 plast = PROF ? otz_cycles () : 0;
 	const u32 lane = otz_lane ();
 	if (n < 1u) {
 		return OZG_ST_DATA;
@@ -722,6 +789,7 @@ OTZ_DEV int otz_zs_block(otz_zs_lds &L, const u8 *p, u32 n, u8 *out, u32 cap, u3
 		used = hdr + comp;
 	}
 	otz_wave_sync (); // the literal buffer is complete
+	OTZ_ZS_MARK (0);
 	p += used;
 	n -= used;
 	// ---- sequences section header
@@ -782,55 +850,81 @@ OTZ_DEV int otz_zs_block(otz_zs_lds &L, const u8 *p, u32 n, u8 *out, u32 cap, u3
 		p += tused;
 		n -= tused;
 		// ---- the bitstream: lane 0 decodes groups of 64 sequences, all lanes execute them
-		otz_zs_bits b;
+		if (n == 0 || p[n - 1u] == 0) {
+			return OZG_ST_DATA; // no end marker
+		}
+		otz_zs_sbits b;
+		b.w = L.sbuf;
+		b.wlo = 0;
+		b.ptr = (i32)n - 8;
+		b.c = 0;
+		b.used = 8u - otz_zs_highbit (p[n - 1u]);
 		u32 sl = 0, so = 0, sm = 0;
 		u32 bad = 0;
-		b.p = p;
-		b.n = n;
-		b.bit = 0;
-		b.c = 0;
-		b.cbit = 0;
-		if (lane == 0) {
-			if (!otz_zs_bits_init (b, p, n)) {
-				bad = 1;
-			} else {
-				sl = otz_zs_read (b, L.ll_log);
-				so = otz_zs_read (b, L.of_log);
-				sm = otz_zs_read (b, L.ml_log);
-				bad = b.bit < 0 ? 1u : 0u;
-			}
-		}
-		if (otz_zs_bcast (bad) != 0) {
-			return OZG_ST_DATA;
-		}
 		u32 r0 = rep[0], r1 = rep[1], r2 = rep[2];
+		i32 wlo = -0x7FFFFFFF; // first stream byte of the staged window (none yet)
+		OTZ_ZS_MARK (1);
 		for (u32 base = 0; base < nseq; base += 64u) {
 			const u32 ng = nseq - base < 64u ? nseq - base : 64u;
+			// the stretch of the bitstream this group can read, into LDS (all lanes; lane 0 then reads it at
+			// LDS latency instead of waiting on global memory): 64 sequences take at most 64 x 105 bits
+			{
+				const i32 ptr = (i32)otz_zs_bcast ((u32)b.ptr) - (i32) (otz_zs_bcast (b.used) >> 3); // lowest byte of the next container
+				const i32 top = ptr + 8; // one past its highest byte
+				if (wlo == -0x7FFFFFFF || ptr - 848 < wlo) {
+					wlo = top > (i32)OTZ_ZS_SBUF ? top - (i32)OTZ_ZS_SBUF : 0;
+					otz_wave_sync_lds ();
+					for (u32 c = lane; c < (OTZ_ZS_SBUF + 32u) / 16u; c += 64u) {
+						// sbuf[16 c ...] = stream bytes [wlo - 16 + 16 c, ...): zeros outside the stream
+						const i32 at = wlo - 16 + 16 * (i32)c;
+						u64 lo8 = 0, hi8 = 0;
+						if (at >= 0) {
+							lo8 = otz_zs_ld64 (p, (u32)at, n);
+							hi8 = otz_zs_ld64 (p, (u32)at + 8u, n);
+						} else if (at + 16 > 0) { // straddles the stream's first byte (wlo < 16)
+							for (i32 k = 0; k < 16; k++) {
+								const i32 q = at + k;
+								const u64 byte = q >= 0 && (u32)q < n ? p[q] : 0u;
+								if (k < 8) {
+									lo8 |= byte << (8 * k);
+								} else {
+									hi8 |= byte << (8 * (k - 8));
+								}
+							}
+						}
+						otz_st64u (&L.sbuf[16u * c], lo8);
+						otz_st64u (&L.sbuf[16u * c + 8u], hi8);
+					}
+					otz_wave_sync_lds ();
+				}
+				b.wlo = wlo;
+			}
+			OTZ_ZS_MARK (4);
 			otz_wave_sync_lds ();
 			if (lane == 0) {
-				for (u32 i = 0; i < ng && !bad; i++) {
+				if (base == 0) {
+					otz_zs_sreload (b);
+					sl = otz_zs_sread (b, L.ll_log);
+					so = otz_zs_sread (b, L.of_log);
+					sm = otz_zs_sread (b, L.ml_log);
+				}
+				for (u32 i = 0; i < ng; i++) {
+					otz_zs_sreload (b); // >= 57 bits in hand: an offset's extra bits (<= 31) fit
 					const u32 el = L.fse_ll[sl], eo = L.fse_of[so], em = L.fse_ml[sm];
-					const u32 lc = el & 0xFFu, oc = eo & 0xFFu, mc = em & 0xFFu;
-					if (lc > 35u || oc > 31u || mc > 52u) {
-						bad = 1;
-						break;
-					}
-					const u32 ov_x = otz_zs_read (b, oc);
-					const u64 ov = ((u64)1 << oc) + ov_x;
-					const u32 mlen = L.ml_base[mc] + otz_zs_read (b, L.ml_bits[mc]);
-					const u32 llen = L.ll_base[lc] + otz_zs_read (b, L.ll_bits[lc]);
+					const u32 oc = eo & 0xFFu; // (<= 31, <= 52, <= 35: the tables hold no other symbols)
+					const u32 mt = L.ml_tab[em & 0xFFu], lt = L.ll_tab[el & 0xFFu];
+					const u32 ov = (1u << oc) + otz_zs_sread (b, oc);
+					otz_zs_sreload (b); // the two lengths' extra bits (<= 16 + 16)
+					const u32 mlen = (mt & 0xFFFFFFu) + otz_zs_sread (b, mt >> 24);
+					const u32 llen = (lt & 0xFFFFFFu) + otz_zs_sread (b, lt >> 24);
 					u32 off;
 					if (ov > 3u) {
-						if (ov - 3u > 0xFFFFFFFFull) {
-							bad = 1;
-							break;
-						}
-						off = (u32) (ov - 3u);
+						off = ov - 3u;
 						r2 = r1;
 						r1 = r0;
 						r0 = off;
 					} else {
-						const u32 idx = (u32)ov - 1u + (llen == 0 ? 1u : 0u);
+						const u32 idx = ov - 1u + (llen == 0 ? 1u : 0u);
 						if (idx == 0) {
 							off = r0;
 						} else {
@@ -843,30 +937,30 @@ OTZ_DEV int otz_zs_block(otz_zs_lds &L, const u8 *p, u32 n, u8 *out, u32 cap, u3
 						}
 					}
 					if (base + i + 1u < nseq) {
-						sl = (el >> 16) + otz_zs_read (b, (el >> 8) & 0xFFu);
-						sm = (em >> 16) + otz_zs_read (b, (em >> 8) & 0xFFu);
-						so = (eo >> 16) + otz_zs_read (b, (eo >> 8) & 0xFFu);
-					}
-					if (b.bit < 0) {
-						bad = 1;
-						break;
+						otz_zs_sreload (b); // three state updates (<= 9 + 9 + 8 bits)
+						sl = (el >> 16) + otz_zs_sread (b, (el >> 8) & 0xFFu);
+						sm = (em >> 16) + otz_zs_sread (b, (em >> 8) & 0xFFu);
+						so = (eo >> 16) + otz_zs_sread (b, (eo >> 8) & 0xFFu);
 					}
 					L.g.g_ll[i] = llen;
 					L.g.g_ml[i] = mlen;
 					L.g.g_off[i] = off;
 				}
-				if (!bad && base + ng == nseq && b.bit != 0) {
-					bad = 1; // the bitstream must be consumed exactly
+				const i32 left = otz_zs_spos (b);
+				if (left < 0 || (base + ng == nseq && left != 0)) {
+					bad = 1; // over-read, or the bitstream was not consumed exactly
 				}
 			}
 			otz_wave_sync_lds ();
 			if (otz_zs_bcast (bad) != 0) {
 				return OZG_ST_DATA;
 			}
-			const int st = otz_zs_execute (L, ng, out, cap, opos, litp, regen, &lpos, frame_start);
+			OTZ_ZS_MARK (2);
+			const int st = otz_zs_execute (L, ng, out, cap, opos, litp, regen, &lpos, frame_start, synced);
 			if (st != 0) {
 				return st;
 			}
+			OTZ_ZS_MARK (3);
 		}
 		rep[0] = otz_zs_bcast (r0);
 		rep[1] = otz_zs_bcast (r1);
@@ -879,7 +973,8 @@ OTZ_DEV int otz_zs_block(otz_zs_lds &L, const u8 *p, u32 n, u8 *out, u32 cap, u3
 	}
 	otz_zs_copy (out + *opos, litp + lpos, rest);
 	*opos += rest;
-	otz_wave_sync ();
+	otz_wave_sync (); // (the literal buffer is rewritten by the next block)
+	*synced = *opos;
 	if (*opos - block_out0 > OTZ_ZS_BLOCK_MAX) {
 		return OZG_ST_DATA;
 	}
@@ -888,15 +983,14 @@ OTZ_DEV int otz_zs_block(otz_zs_lds &L, const u8 *p, u32 n, u8 *out, u32 cap, u3
 
 // Every frame of in[0, n_in) (skippable frames skipped).  All 64 lanes.  lit: the wavefront's
 // OTZ_ZS_LIT_BYTES of global scratch.  Returns OZG_ST_OK (with *total) or the failure.
-OTZ_DEV int otz_zs_entry(otz_zs_lds &L, const u8 *in, u32 n_in, u8 *out, u32 cap, u8 *lit, u32 *total) {
+template <bool PROF>
+OTZ_DEV int otz_zs_entry(otz_zs_lds &L, const u8 *in, u32 n_in, u8 *out, u32 cap, u8 *lit, u32 *total, u64 *pc) {
 	const u32 lane = otz_lane ();
 	for (u32 i = lane; i < 36u; i += 64u) {
-		L.ll_base[i] = otz_zs_ll_base_c[i];
-		L.ll_bits[i] = otz_zs_ll_bits_c[i];
+		L.ll_tab[i] = otz_zs_ll_base_c[i] | ((u32)otz_zs_ll_bits_c[i] << 24);
 	}
 	for (u32 i = lane; i < 53u; i += 64u) {
-		L.ml_base[i] = otz_zs_ml_base_c[i];
-		L.ml_bits[i] = otz_zs_ml_bits_c[i];
+		L.ml_tab[i] = otz_zs_ml_base_c[i] | ((u32)otz_zs_ml_bits_c[i] << 24);
 	}
 	otz_wave_sync_lds ();
 	u32 ip = 0, opos = 0, frames = 0;
@@ -954,6 +1048,7 @@ OTZ_DEV int otz_zs_entry(otz_zs_lds &L, const u8 *in, u32 n_in, u8 *out, u32 cap
 		}
 		h += fcs_len;
 		const u32 frame_start = opos;
+		u32 synced = opos; // (frames before this one ended with a fence)
 		u32 rep[3] = { 1u, 4u, 8u };
 		if (lane == 0) {
 			L.huf_log = 0;
@@ -980,7 +1075,6 @@ OTZ_DEV int otz_zs_entry(otz_zs_lds &L, const u8 *in, u32 n_in, u8 *out, u32 cap
 					return OZG_ST_SIZE;
 				}
 				otz_zs_copy (out + opos, in + h, bs);
-				otz_wave_sync ();
 				opos += bs;
 				h += bs;
 			} else if (type == 1u) {
@@ -991,20 +1085,20 @@ OTZ_DEV int otz_zs_entry(otz_zs_lds &L, const u8 *in, u32 n_in, u8 *out, u32 cap
 					return OZG_ST_SIZE;
 				}
 				otz_zs_fill (out + opos, in[h], bs);
-				otz_wave_sync ();
 				opos += bs;
 				h += 1u;
 			} else {
 				if (bs > n_in - h) {
 					return OZG_ST_DATA;
 				}
-				const int st = otz_zs_block (L, in + h, bs, out, cap, &opos, lit, frame_start, rep);
+				const int st = otz_zs_block<PROF> (L, in + h, bs, out, cap, &opos, lit, frame_start, rep, &synced, pc);
 				if (st != 0) {
 					return st;
 				}
 				h += bs;
 			}
 		}
+		otz_wave_sync (); // the frame's bytes are in memory (checksum below, next frame, CRC kernel)
 		if (fcs_len && (u64) (opos - frame_start) != fcs) {
 			return OZG_ST_DATA;
 		}
@@ -1013,8 +1107,12 @@ OTZ_DEV int otz_zs_entry(otz_zs_lds &L, const u8 *in, u32 n_in, u8 *out, u32 cap
 				return OZG_ST_DATA;
 			}
 			const u32 want = (u32)in[h] | ((u32)in[h + 1u] << 8) | ((u32)in[h + 2u] << 16) | ((u32)in[h + 3u] << 24);
+			const u64 t0 = PROF ? otz_cycles () : 0;
 			if ((u32)otz_zs_xxh64 (out + frame_start, opos - frame_start) != want) {
 				return OZG_ST_DATA;
+			}
+			if (PROF) {
+				pc[5] += otz_cycles () - t0;
 			}
 			h += 4u;
 		}
@@ -1041,9 +1139,18 @@ OTZ_DEV bool otz_zs_is_candidate(const u8 *in, u32 n_in) {
 }
 
 // One method-93 entry.  All 64 lanes.  Writes *res and route (lane 0).
-OTZ_DEV void otz_zs_run(otz_zs_lds &L, const u8 *in, u32 n_in, u8 *out, u32 cap, u8 *lit, ozg_result *res, u8 *route) {
+template <bool PROF = false>
+OTZ_DEV void otz_zs_run(otz_zs_lds &L, const u8 *in, u32 n_in, u8 *out, u32 cap, u8 *lit, ozg_result *res, u8 *route, u64 *prof = nullptr) {
 	u32 total = 0;
-	const int st = otz_zs_entry (L, in, n_in, out, cap, lit, &total);
+	u64 pc[6] = { 0, 0, 0, 0, 0, 0 };
+	const u64 t0 = PROF ? otz_cycles () : 0;
+	const int st = otz_zs_entry<PROF> (L, in, n_in, out, cap, lit, &total, pc);
+	if (PROF && prof && otz_lane () == 0) {
+		for (u32 i = 0; i < 6u; i++) {
+			prof[i] = pc[i];
+		}
+		prof[15] = otz_cycles () - t0;
+	}
 	if (otz_lane () == 0) {
 		if (st == OZG_ST_OK && total == cap) {
 			res->status = OZG_ST_OK;

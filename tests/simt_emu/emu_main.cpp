@@ -64,7 +64,7 @@ void *thread_main(void *p) {
 		// what otz_zstd_kernel does for one entry
 		const ozg_entry &e = *a->e;
 		if (!otz_zipbomb (e, a->lim) && otz_zs_is_candidate (a->src + e.src_off, e.comp_size)) {
-			otz_zs_run (*(otz_zs_lds *)a->lds, a->src + e.src_off, e.comp_size, a->dst + e.dst_off, e.uncomp_size, a->zs_lit, a->r, a->zs_route);
+			otz_zs_run<false> (*(otz_zs_lds *)a->lds, a->src + e.src_off, e.comp_size, a->dst + e.dst_off, e.uncomp_size, a->zs_lit, a->r, a->zs_route);
 		}
 	} else if (a->phase == 5) {
 		// what otz_zstd_crc_kernel does

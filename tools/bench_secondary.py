@@ -62,11 +62,22 @@ def main():
     arc_m, ents_m = corpus.build_archive(n, 65536, methods=(100, 97))
     arc_d, ents_d = corpus.build_archive(min(n, 4000), 65536, methods=(8,))
     bufs = corpus.text_buffers(min(n, 10000), 65536, first=50000)
+    arc_rz = ents_rz = None
+    try:  # real Zstandard frames (libzstd of the image makes them): configs[2] shape, and 64 KiB entries like configs[1]
+        arc_rz, ents_rz = corpus.build_zstd_real(max(n // 4, 100), 262144)
+        arc_rz64, ents_rz64 = corpus.build_zstd_real(n, 65536)
+    except Exception as ex:  # no libzstd: nothing to measure
+        print("real zstd corpus unavailable: %r" % (ex,), file=sys.stderr)
     oz.init(0)
     L = oz.lib()
     dev = torch.device("cuda", 0)
     report["zstd93_256KiB_decode"] = decode_resident(arc_z, ents_z, oz.BATCH_NO_DEFLATE)
-    report["lzfse100_brot97_64KiB_decode"] = decode_resident(arc_m, ents_m, oz.BATCH_NO_DEFLATE)
+    report["lzfse100_brot97_64KiB_decode"] = decode_resident(arc_m, ents_m, oz.BATCH_NO_DEFLATE | oz.BATCH_NO_ZSTD)
+    if arc_rz is not None:
+        report["zstd_rfc8878_256KiB_decode"] = dict(decode_resident(arc_rz, ents_rz, oz.BATCH_NO_DEFLATE), entries=len(ents_rz),
+                                                      note="real Zstandard frames, libzstd level 3 with content checksum")
+        report["zstd_rfc8878_64KiB_decode"] = dict(decode_resident(arc_rz64, ents_rz64, oz.BATCH_NO_DEFLATE), entries=len(ents_rz64),
+                                                     note="real Zstandard frames, libzstd level 3 with content checksum")
     # encode, resident
     nb = len(bufs)
     ents = (N.OzgEncEntry * nb)()

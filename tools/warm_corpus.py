@@ -19,6 +19,11 @@ def main():
     for k in (2000, 4000, 10000):
         corpus.build_archive(k, 65536)
     corpus.text_buffers(10000, 65536, first=50000)
+    try:
+        corpus.build_zstd_real(max(n // 4, 100), 262144)
+        corpus.build_zstd_real(n, 65536)
+    except Exception as ex:
+        print("real zstd corpus unavailable: %r" % (ex,))
     print("corpora cached")
 
 
