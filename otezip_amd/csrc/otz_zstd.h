@@ -49,7 +49,7 @@ typedef int64_t i64;
 
 struct otz_zs_lds {
 	u16 huf[1u << OTZ_ZS_HUF_LOG_MAX]; // literal code: symbol | bits << 8
-	u32 fse_ll[512], fse_ml[512], fse_of[256]; // symbol | state bits << 8 | baseline << 16
+	u32 fse_ll[512], fse_ml[512], fse_of[256]; // entries: OTZ_ZS_E_* below
 	u32 ll_tab[36], ml_tab[53]; // baseline | extra bits << 24 of the literal-length / match-length codes
 	union {
 		struct { // a group of sequences and the prefix arrays of its flattened copies
@@ -177,6 +177,19 @@ OTZ_DEV u32 otz_zs_peek(otz_zs_bits &b, u32 nb) {
 	return v << sh;
 }
 
+// default distributions (RFC 8878 3.1.1.3.2.2.x)
+OTZ_CONST_TABLE int8_t otz_zs_ll_def[36] = { 4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1 };
+OTZ_CONST_TABLE int8_t otz_zs_ml_def[53] = { 1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+	1, 1, 1, -1, -1, -1, -1, -1, -1, -1 };
+OTZ_CONST_TABLE int8_t otz_zs_of_def[29] = { 1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1 };
+OTZ_CONST_TABLE u32 otz_zs_ll_base_c[36] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 28, 32, 40, 48, 64, 128, 256, 512, 1024, 2048,
+	4096, 8192, 16384, 32768, 65536 };
+OTZ_CONST_TABLE u8 otz_zs_ll_bits_c[36] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16 };
+OTZ_CONST_TABLE u32 otz_zs_ml_base_c[53] = { 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35,
+	37, 39, 41, 43, 47, 51, 59, 67, 83, 99, 131, 259, 515, 1027, 2051, 4099, 8195, 16387, 32771, 65539 };
+OTZ_CONST_TABLE u8 otz_zs_ml_bits_c[53] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5,
+	7, 8, 9, 10, 11, 12, 13, 14, 15, 16 };
+
 // ---------------------------------------------------------------- FSE (lane 0)
 
 // forward bit reader over a byte range for table descriptions
@@ -252,8 +265,32 @@ OTZ_DEV_NOINLINE u32 otz_zs_read_norm(otz_zs_lds &L, const u8 *p, u32 n, u32 *ns
 	return (bit + 7u) / 8u;
 }
 
+// Table entry: [5:0] symbol, [10:6] the symbol's extra-bit count (sequence tables; so that the bit
+// positions of a sequence follow from its three entries alone, without waiting for the baseline
+// lookups), [15:11] bits of the state update, [31:16] its baseline.
+#define OTZ_ZS_E_SYM(e) ((e) & 63u)
+#define OTZ_ZS_E_ADD(e) (((e) >> 6) & 31u)
+#define OTZ_ZS_E_NB(e) (((e) >> 11) & 31u)
+#define OTZ_ZS_E_BASE(e) ((e) >> 16)
+#define OTZ_ZS_KIND_LL 0u
+#define OTZ_ZS_KIND_ML 1u
+#define OTZ_ZS_KIND_OF 2u
+#define OTZ_ZS_KIND_WEIGHTS 3u
+OTZ_DEV u32 otz_zs_extra_bits(const otz_zs_lds &L, u32 kind, u32 sym) {
+	if (kind == OTZ_ZS_KIND_OF) {
+		return sym;
+	}
+	if (kind == OTZ_ZS_KIND_LL) {
+		return L.ll_tab[sym < 36u ? sym : 0u] >> 24; // (the LDS copies: a constant-memory load per table cell is slow)
+	}
+	if (kind == OTZ_ZS_KIND_ML) {
+		return L.ml_tab[sym < 53u ? sym : 0u] >> 24;
+	}
+	return 0;
+}
+
 // decoding table from L.b.norm[0..nsym) (RFC 8878 4.1.1); false on an inconsistent distribution
-OTZ_DEV_NOINLINE bool otz_zs_fse_build(otz_zs_lds &L, u32 *tab, u32 nsym, u32 log) {
+OTZ_DEV_NOINLINE bool otz_zs_fse_build(otz_zs_lds &L, u32 *tab, u32 nsym, u32 log, u32 kind) {
 	const u32 size = 1u << log;
 	i32 high = (i32)size - 1;
 	for (u32 s = 0; s < nsym; s++) {
@@ -284,32 +321,19 @@ OTZ_DEV_NOINLINE bool otz_zs_fse_build(otz_zs_lds &L, u32 *tab, u32 nsym, u32 lo
 		const u32 s = L.b.spread[i];
 		const u32 x = L.b.next[s]++;
 		const u32 nb = log - otz_zs_highbit (x);
-		tab[i] = s | (nb << 8) | ((((x << nb) - size) & 0xFFFFu) << 16);
+		tab[i] = s | (otz_zs_extra_bits (L, kind, s) << 6) | (nb << 11) | ((((x << nb) - size) & 0xFFFFu) << 16);
 	}
 	return true;
 }
 
-// default distributions (RFC 8878 3.1.1.3.2.2.x)
-OTZ_CONST_TABLE int8_t otz_zs_ll_def[36] = { 4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1 };
-OTZ_CONST_TABLE int8_t otz_zs_ml_def[53] = { 1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
-	1, 1, 1, -1, -1, -1, -1, -1, -1, -1 };
-OTZ_CONST_TABLE int8_t otz_zs_of_def[29] = { 1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1 };
-OTZ_CONST_TABLE u32 otz_zs_ll_base_c[36] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 28, 32, 40, 48, 64, 128, 256, 512, 1024, 2048,
-	4096, 8192, 16384, 32768, 65536 };
-OTZ_CONST_TABLE u8 otz_zs_ll_bits_c[36] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16 };
-OTZ_CONST_TABLE u32 otz_zs_ml_base_c[53] = { 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35,
-	37, 39, 41, 43, 47, 51, 59, 67, 83, 99, 131, 259, 515, 1027, 2051, 4099, 8195, 16387, 32771, 65539 };
-OTZ_CONST_TABLE u8 otz_zs_ml_bits_c[53] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5,
-	7, 8, 9, 10, 11, 12, 13, 14, 15, 16 };
-
 // one of the three sequence tables (lane 0); returns bytes used, or 0xFFFFFFFF on error
 OTZ_DEV_NOINLINE u32 otz_zs_seq_table(otz_zs_lds &L, u32 *tab, u32 *log, u32 *have, u32 mode, const u8 *p, u32 n, const int8_t *def, u32 def_n, u32 def_log,
-	u32 max_log, u32 max_sym) {
+	u32 max_log, u32 max_sym, u32 kind) {
 	if (mode == 0) {
 		for (u32 s = 0; s < def_n; s++) {
 			L.b.norm[s] = def[s];
 		}
-		if (!otz_zs_fse_build (L, tab, def_n, def_log)) {
+		if (!otz_zs_fse_build (L, tab, def_n, def_log, kind)) {
 			return 0xFFFFFFFFu;
 		}
 		*log = def_log;
@@ -320,7 +344,7 @@ OTZ_DEV_NOINLINE u32 otz_zs_seq_table(otz_zs_lds &L, u32 *tab, u32 *log, u32 *ha
 		if (n < 1u || p[0] > max_sym) {
 			return 0xFFFFFFFFu;
 		}
-		tab[0] = p[0];
+		tab[0] = p[0] | (otz_zs_extra_bits (L, kind, p[0]) << 6);
 		*log = 0;
 		*have = 1;
 		return 1;
@@ -328,7 +352,7 @@ OTZ_DEV_NOINLINE u32 otz_zs_seq_table(otz_zs_lds &L, u32 *tab, u32 *log, u32 *ha
 	if (mode == 2) {
 		u32 nsym = 0, al = 0;
 		const u32 used = otz_zs_read_norm (L, p, n, &nsym, &al, max_log, max_sym);
-		if (used == 0 || !otz_zs_fse_build (L, tab, nsym, al)) {
+		if (used == 0 || !otz_zs_fse_build (L, tab, nsym, al, kind)) {
 			return 0xFFFFFFFFu;
 		}
 		*log = al;
@@ -368,7 +392,7 @@ OTZ_DEV_NOINLINE u32 otz_zs_read_tree(otz_zs_lds &L, const u8 *p, u32 n) {
 			return 0;
 		}
 		u32 *tab = L.b.wtab;
-		if (!otz_zs_fse_build (L, tab, nsym, log)) {
+		if (!otz_zs_fse_build (L, tab, nsym, log, OTZ_ZS_KIND_WEIGHTS)) {
 			return 0;
 		}
 		otz_zs_bits b;
@@ -383,23 +407,23 @@ OTZ_DEV_NOINLINE u32 otz_zs_read_tree(otz_zs_lds &L, const u8 *p, u32 n) {
 			if (nw >= 254u) {
 				return 0;
 			}
-			L.b.weights[nw++] = (u8) (tab[s1] & 0xFFu);
-			u32 nb = (tab[s1] >> 8) & 0xFFu;
+			L.b.weights[nw++] = (u8)OTZ_ZS_E_SYM (tab[s1]);
+			u32 nb = OTZ_ZS_E_NB (tab[s1]);
 			if (b.bit < (i32)nb) {
-				L.b.weights[nw++] = (u8) (tab[s2] & 0xFFu);
+				L.b.weights[nw++] = (u8)OTZ_ZS_E_SYM (tab[s2]);
 				break;
 			}
-			s1 = (tab[s1] >> 16) + otz_zs_read (b, nb);
+			s1 = OTZ_ZS_E_BASE (tab[s1]) + otz_zs_read (b, nb);
 			if (nw >= 254u) {
 				return 0;
 			}
-			L.b.weights[nw++] = (u8) (tab[s2] & 0xFFu);
-			nb = (tab[s2] >> 8) & 0xFFu;
+			L.b.weights[nw++] = (u8)OTZ_ZS_E_SYM (tab[s2]);
+			nb = OTZ_ZS_E_NB (tab[s2]);
 			if (b.bit < (i32)nb) {
-				L.b.weights[nw++] = (u8) (tab[s1] & 0xFFu);
+				L.b.weights[nw++] = (u8)OTZ_ZS_E_SYM (tab[s1]);
 				break;
 			}
-			s2 = (tab[s2] >> 16) + otz_zs_read (b, nb);
+			s2 = OTZ_ZS_E_BASE (tab[s2]) + otz_zs_read (b, nb);
 		}
 	}
 	u32 total = 0;
@@ -598,16 +622,36 @@ OTZ_DEV void otz_zs_fill(u8 *dst, u32 v, u32 n) {
 OTZ_DEV u64 otz_rotl64(u64 x, u32 r) { return (x << r) | (x >> (64u - r)); }
 OTZ_DEV u64 otz_xround(u64 acc, u64 in) { return otz_rotl64 (acc + in * OTZ_XP2, 31) * OTZ_XP1; }
 OTZ_DEV u64 otz_xmerge(u64 h, u64 v) { return (h ^ otz_xround (0, v)) * OTZ_XP1 + OTZ_XP4; }
-// all lanes call; lanes 0-3 run the four accumulators, every lane gets the digest
-OTZ_DEV_NOINLINE u64 otz_zs_xxh64(const u8 *p, u32 n) {
+// all lanes call; lanes 0-3 run the four accumulators, every lane gets the digest.  The input streams
+// through LDS a kilobyte at a time (every lane loads 16 bytes, the next kilobyte is already on its way
+// while the four lanes work through the 32 stripes of this one): the accumulators' chain of 64-bit
+// multiplications then never waits for global memory.
+OTZ_DEV_NOINLINE u64 otz_zs_xxh64(otz_zs_lds &L, const u8 *p, u32 n) {
 	const u32 lane = otz_lane ();
 	const u32 stripes = n >> 5;
 	u64 v = lane == 0 ? OTZ_XP1 + OTZ_XP2 : lane == 1u ? OTZ_XP2 : lane == 2u ? 0ull : 0ull - OTZ_XP1;
-	if (lane < 4u) {
-		for (u32 s = 0; s < stripes; s++) {
-			v = otz_xround (v, otz_ld64u (p + 32u * s + 8u * lane));
+	const u32 chunks = (stripes + 31u) >> 5; // of 1 KiB
+	otz_u4 nx = { 0, 0, 0, 0 };
+	if (chunks && 16u * lane + 16u <= n) {
+		nx = otz_ld16 (p + 16u * lane);
+	}
+	for (u32 c = 0; c < chunks; c++) {
+		otz_wave_sync_lds ();
+		otz_st64u (&L.sbuf[16u * lane], (u64)nx.x | ((u64)nx.y << 32));
+		otz_st64u (&L.sbuf[16u * lane + 8u], (u64)nx.z | ((u64)nx.w << 32));
+		otz_wave_sync_lds ();
+		const u32 nat = 1024u * (c + 1u) + 16u * lane;
+		if (c + 1u < chunks && nat + 16u <= n) {
+			nx = otz_ld16 (p + nat);
+		}
+		if (lane < 4u) {
+			const u32 ns = stripes - 32u * c < 32u ? stripes - 32u * c : 32u;
+			for (u32 k = 0; k < ns; k++) {
+				v = otz_xround (v, otz_ld64u (&L.sbuf[32u * k + 8u * lane]));
+			}
 		}
 	}
+	otz_wave_sync_lds ();
 	const u32 v0l = otz_readlane ((u32)v, 0), v0h = otz_readlane ((u32) (v >> 32), 0);
 	const u32 v1l = otz_readlane ((u32)v, 1), v1h = otz_readlane ((u32) (v >> 32), 1);
 	const u32 v2l = otz_readlane ((u32)v, 2), v2h = otz_readlane ((u32) (v >> 32), 2);
@@ -831,14 +875,14 @@ OTZ_DEV int otz_zs_block(otz_zs_lds &L, const u8 *p, u32 n, u8 *out, u32 cap, u3
 		otz_wave_sync_lds ();
 		if (lane == 0) {
 			u32 at = 0;
-			u32 u = otz_zs_seq_table (L, L.fse_ll, &L.ll_log, &L.have_ll, (modes >> 6) & 3u, p, n, otz_zs_ll_def, 36, 6, 9, 35);
+			u32 u = otz_zs_seq_table (L, L.fse_ll, &L.ll_log, &L.have_ll, (modes >> 6) & 3u, p, n, otz_zs_ll_def, 36, 6, 9, 35, OTZ_ZS_KIND_LL);
 			if (u != 0xFFFFFFFFu) {
 				at = u;
-				u = otz_zs_seq_table (L, L.fse_of, &L.of_log, &L.have_of, (modes >> 4) & 3u, p + at, n - at, otz_zs_of_def, 29, 5, 8, 31);
+				u = otz_zs_seq_table (L, L.fse_of, &L.of_log, &L.have_of, (modes >> 4) & 3u, p + at, n - at, otz_zs_of_def, 29, 5, 8, 31, OTZ_ZS_KIND_OF);
 			}
 			if (u != 0xFFFFFFFFu) {
 				at += u;
-				u = otz_zs_seq_table (L, L.fse_ml, &L.ml_log, &L.have_ml, (modes >> 2) & 3u, p + at, n - at, otz_zs_ml_def, 53, 6, 9, 52);
+				u = otz_zs_seq_table (L, L.fse_ml, &L.ml_log, &L.have_ml, (modes >> 2) & 3u, p + at, n - at, otz_zs_ml_def, 53, 6, 9, 52, OTZ_ZS_KIND_ML);
 			}
 			tused = u == 0xFFFFFFFFu ? u : at + u;
 		}
@@ -909,14 +953,26 @@ OTZ_DEV int otz_zs_block(otz_zs_lds &L, const u8 *p, u32 n, u8 *out, u32 cap, u3
 					sm = otz_zs_sread (b, L.ml_log);
 				}
 				for (u32 i = 0; i < ng; i++) {
+					// The chain that limits this loop is state -> table entry -> next state.  The entries carry their
+					// symbols' extra-bit counts, so every bit position of the sequence follows from them at once;
+					// the baseline lookups (ll_tab / ml_tab) are off that chain.
 					otz_zs_sreload (b); // >= 57 bits in hand: an offset's extra bits (<= 31) fit
 					const u32 el = L.fse_ll[sl], eo = L.fse_of[so], em = L.fse_ml[sm];
-					const u32 oc = eo & 0xFFu; // (<= 31, <= 52, <= 35: the tables hold no other symbols)
-					const u32 mt = L.ml_tab[em & 0xFFu], lt = L.ll_tab[el & 0xFFu];
-					const u32 ov = (1u << oc) + otz_zs_sread (b, oc);
+					const u32 oc = OTZ_ZS_E_ADD (eo), mb = OTZ_ZS_E_ADD (em), lb = OTZ_ZS_E_ADD (el);
+					const u32 mt = L.ml_tab[OTZ_ZS_E_SYM (em)], lt = L.ll_tab[OTZ_ZS_E_SYM (el)];
+					const u32 ox = otz_zs_sread (b, oc);
 					otz_zs_sreload (b); // the two lengths' extra bits (<= 16 + 16)
-					const u32 mlen = (mt & 0xFFFFFFu) + otz_zs_sread (b, mt >> 24);
-					const u32 llen = (lt & 0xFFFFFFu) + otz_zs_sread (b, lt >> 24);
+					const u32 mx = otz_zs_sread (b, mb);
+					const u32 lx = otz_zs_sread (b, lb);
+					if (base + i + 1u < nseq) {
+						otz_zs_sreload (b); // three state updates (<= 9 + 9 + 8 bits)
+						sl = OTZ_ZS_E_BASE (el) + otz_zs_sread (b, OTZ_ZS_E_NB (el));
+						sm = OTZ_ZS_E_BASE (em) + otz_zs_sread (b, OTZ_ZS_E_NB (em));
+						so = OTZ_ZS_E_BASE (eo) + otz_zs_sread (b, OTZ_ZS_E_NB (eo));
+					}
+					const u32 ov = (1u << oc) + ox;
+					const u32 mlen = (mt & 0xFFFFFFu) + mx;
+					const u32 llen = (lt & 0xFFFFFFu) + lx;
 					u32 off;
 					if (ov > 3u) {
 						off = ov - 3u;
@@ -935,12 +991,6 @@ OTZ_DEV int otz_zs_block(otz_zs_lds &L, const u8 *p, u32 n, u8 *out, u32 cap, u3
 							r1 = r0;
 							r0 = off;
 						}
-					}
-					if (base + i + 1u < nseq) {
-						otz_zs_sreload (b); // three state updates (<= 9 + 9 + 8 bits)
-						sl = (el >> 16) + otz_zs_sread (b, (el >> 8) & 0xFFu);
-						sm = (em >> 16) + otz_zs_sread (b, (em >> 8) & 0xFFu);
-						so = (eo >> 16) + otz_zs_sread (b, (eo >> 8) & 0xFFu);
 					}
 					L.g.g_ll[i] = llen;
 					L.g.g_ml[i] = mlen;
@@ -1108,7 +1158,7 @@ OTZ_DEV int otz_zs_entry(otz_zs_lds &L, const u8 *in, u32 n_in, u8 *out, u32 cap
 			}
 			const u32 want = (u32)in[h] | ((u32)in[h + 1u] << 8) | ((u32)in[h + 2u] << 16) | ((u32)in[h + 3u] << 24);
 			const u64 t0 = PROF ? otz_cycles () : 0;
-			if ((u32)otz_zs_xxh64 (out + frame_start, opos - frame_start) != want) {
+			if ((u32)otz_zs_xxh64 (L, out + frame_start, opos - frame_start) != want) {
 				return OZG_ST_DATA;
 			}
 			if (PROF) {
