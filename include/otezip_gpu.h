@@ -167,6 +167,9 @@ typedef struct ozg_enc_entry {
  * method -- DEFLATE, or the reference's private 93 / 100 / 97 / 14 framings, byte-exact --
  * never fall back to STORE; OZG_ST_BUF if dst_cap is too small. */
 #define OZG_ENC_F_CODEC_ONLY 1u
+/* report the Adler-32 of the input in ozg_enc_result.crc32 instead of its CRC-32 (the zlib framing of the
+ * z_stream seam, RFC 1950, ends with it) */
+#define OZG_ENC_F_ADLER32 2u
 
 /* 16 bytes */
 typedef struct ozg_enc_result {
@@ -198,6 +201,10 @@ int ozg_encode_submit(const void *h_src, uint64_t src_len, void *h_dst, uint64_t
  * writer of zip_close uses: the worst-case slot layout is 2-3 x the bytes that matter. */
 int ozg_encode_submit_packed(const void *h_src, uint64_t src_len, void *h_dst, uint64_t dst_len,
 	const ozg_enc_entry *entries, ozg_enc_result *h_results, uint32_t n, ozg_job **job);
+
+/* Checksum of a host buffer on the device (one call = H2D, one kernel, 4 bytes back): kind 0 = CRC-32,
+ * 1 = Adler-32.  What inflate() of the z_stream seam verifies a zlib / gzip trailer with. */
+int ozg_checksum_host(int kind, const void *buf, uint64_t len, uint32_t *out);
 
 /* crc[i] = CRC-32 of d_buf[off[i] .. off[i]+len[i]) (all device pointers). */
 int ozg_crc32_batch_device(const void *d_buf, const uint64_t *d_off, const uint32_t *d_len, uint32_t *d_crc,

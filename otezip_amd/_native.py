@@ -63,6 +63,7 @@ ABI = {
     "ozg_current_device": (C.c_int, []),
     "ozg_decode_submit": (C.c_int, [_VP, _U64, _VP, _U64, C.POINTER(OzgEntry), _VP, _U32, C.POINTER(_VP)]),
     "ozg_encode_submit": (C.c_int, [_VP, _U64, _VP, _U64, _VP, _VP, _U32, C.POINTER(_VP)]),
+    "ozg_checksum_host": (C.c_int, [C.c_int, _VP, _U64, C.POINTER(C.c_uint32)]),
     "ozg_encode_submit_packed": (C.c_int, [_VP, _U64, _VP, _U64, _VP, _VP, _U32, C.POINTER(_VP)]),
     "ozg_job_done": (C.c_int, [_VP]),
     "ozg_job_wait": (C.c_int, [_VP]),

@@ -150,3 +150,38 @@ OTZ_DEV u32 otz_block_xor(u32 v, u32 *scratch) {
 	}
 	return r;
 }
+
+// Adler-32 (RFC 1950) of p[0, n) by a workgroup of NT work-items (NT <= 256); every work-item gets it.
+// A = 1 + sum d_i, B = n + sum (n - i) d_i, both mod 65521: each work-item sums a contiguous slice in 64-bit
+// registers (no reduction needed inside a slice of < 2^24 bytes: 255 * m^2 / 2 < 2^63), the slices are
+// stitched with B += a_t * (bytes behind slice t).  scratch: 2 * NT u64 in LDS.
+OTZ_DEV u32 otz_adler32_block(const u8 *p, u32 n, u64 *scratch) {
+	const u32 tid = otz_tid (), nt = otz_nthreads ();
+	const u32 M = 65521u;
+	const u32 per = (n + nt - 1u) / nt;
+	const u32 i0 = (u64)tid * per < n ? tid * per : n, i1 = i0 + per < n ? i0 + per : n;
+	u64 a = 0, b = 0;
+	u32 i = i0;
+	for (; i < i1; i++) {
+		const u64 d = p[i];
+		a += d;
+		b += d * (u64) (i1 - i);
+		if (((i - i0) & 0xFFFFFu) == 0xFFFFFu) { // (slices longer than a megabyte: keep the sums small)
+			a %= M;
+			b %= M;
+		}
+	}
+	a %= M;
+	b %= M;
+	b = (b + a * ((u64) (n - i1) % M)) % M;
+	scratch[tid] = a;
+	scratch[nt + tid] = b;
+	otz_sync ();
+	u64 A = 1, B = (u64)n % M;
+	for (u32 t = 0; t < nt; t++) {
+		A += scratch[t];
+		B += scratch[nt + t];
+	}
+	otz_sync ();
+	return (u32) (A % M) | ((u32) (B % M) << 16);
+}

@@ -257,6 +257,26 @@ otz_crc32_kernel(const u8 *buf, const u64 *off, const u32 *len, u32 *crc, u32 n)
 	}
 }
 
+// CRC-32 (kind 0) or Adler-32 (kind 1) of one buffer
+extern "C" __global__ void __launch_bounds__ (256)
+otz_checksum_kernel(const u8 *buf, u32 n, u32 kind, u32 *out) {
+	extern __shared__ __attribute__ ((aligned (16))) u8 otz_smem[];
+	otz_copy_lds &L = *reinterpret_cast<otz_copy_lds *> (otz_smem);
+	u32 v;
+	if (kind == 1u) {
+		v = otz_adler32_block (buf, n, reinterpret_cast<u64 *> (L.t4));
+	} else {
+		otz_crc_load_slice4 (L.t4);
+		otz_crc_load_adv4k (L.a4);
+		otz_sync ();
+		const u32 R = otz_stream_crc (L, buf, nullptr, n, false);
+		v = ~(otz_gf_mul (0xFFFFFFFFu, otz_xpow_bytes (n)) ^ R);
+	}
+	if (otz_tid () == 0) {
+		*out = v;
+	}
+}
+
 // DEFLATE encode / STORE of n independent buffers: one wavefront per buffer (20 KB LDS).  The grid is
 // persistent -- as many wavefronts as fit the chip, each taking the next buffer off a counter -- so
 // that the token scratch (OTZ_ENC_TOK_WORDS words per wavefront) is sized by the chip, not the batch.
@@ -322,6 +342,13 @@ otz_enc_crc_kernel(const u8 *src, u8 *dst, const ozg_enc_entry *entries, ozg_enc
 	otz_crc_load_adv4k (L.a4);
 	otz_sync ();
 	u32 m = entries[i].src_size;
+	if (entries[i].reserved & OZG_ENC_F_ADLER32) {
+		const u32 ad = otz_adler32_block (src + entries[i].src_off, m, reinterpret_cast<u64 *> (L.t4));
+		if (otz_tid () == 0) {
+			results[i].crc32 = ad;
+		}
+		return;
+	}
 	u32 R = otz_stream_crc (L, src + entries[i].src_off, nullptr, m, false);
 	if (otz_tid () == 0) {
 		const u32 crc = ~(otz_gf_mul (0xFFFFFFFFu, otz_xpow_bytes (m)) ^ R);
@@ -852,6 +879,7 @@ int ozg_init(int device) {
 		OZG_HIP (hipFuncSetAttribute ((const void *)otz_zstd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof (otz_zs_lds)));
 		OZG_HIP (hipFuncSetAttribute ((const void *)otz_zstd_prof_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof (otz_zs_lds)));
 		OZG_HIP (hipFuncSetAttribute ((const void *)otz_zstd_crc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof (otz_copy_lds)));
+		OZG_HIP (hipFuncSetAttribute ((const void *)otz_checksum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof (otz_copy_lds)));
 		int cus = 256, per_cu = 16;
 		(void)hipDeviceGetAttribute (&cus, hipDeviceAttributeMultiprocessorCount, phys_of (device));
 		(void)hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu, otz_index_kernel, 64, sizeof (otz_k1_lds));
@@ -1338,6 +1366,31 @@ int ozg_encode_batch_host(const void *src, uint64_t src_len, void *dst, uint64_t
 	}
 	OZG_HIP (hipMemcpyAsync (dst, S.d_dst, dst_len, hipMemcpyDeviceToHost, nullptr));
 	OZG_HIP (hipMemcpyAsync (results, S.d_res, (size_t)n * sizeof (ozg_enc_result), hipMemcpyDeviceToHost, nullptr));
+	OZG_HIP (hipStreamSynchronize (nullptr));
+	return OZG_OK;
+}
+
+int ozg_checksum_host(int kind, const void *buf, uint64_t len, uint32_t *out) {
+	dev_ctx *C;
+	int rc = need_ctx (&C);
+	if (rc != OZG_OK) {
+		return rc;
+	}
+	if (!out || (!buf && len) || len > 0xFFFFFFFFull || (kind != 0 && kind != 1)) {
+		snprintf (g_err, sizeof (g_err), "ozg_checksum_host: bad argument");
+		return OZG_E_ARG;
+	}
+	std::lock_guard<std::mutex> lk (g_mu);
+	staging &S = C->stage;
+	if ((rc = staging_reserve (S, len + 64, 64, 64, 64)) != OZG_OK) {
+		return rc;
+	}
+	if (len) {
+		OZG_HIP (hipMemcpyAsync (S.d_src, buf, len, hipMemcpyHostToDevice, nullptr));
+	}
+	hipLaunchKernelGGL (otz_checksum_kernel, dim3 (1), dim3 (256), sizeof (otz_copy_lds), nullptr, (const u8 *)S.d_src, (u32)len, (u32)kind, (u32 *)S.d_res);
+	OZG_HIP (hipGetLastError ());
+	OZG_HIP (hipMemcpyAsync (out, S.d_res, 4, hipMemcpyDeviceToHost, nullptr));
 	OZG_HIP (hipStreamSynchronize (nullptr));
 	return OZG_OK;
 }

@@ -13,29 +13,40 @@
  * buffer in one call.  That is the contract implemented here: ONE call of inflate() /
  * deflate() / <codec>Compress() / <codec>Decompress() runs the GPU batch path (a batch of one)
  * over next_in[0, avail_in) into next_out[0, avail_out).  There is no CPU codec behind these
- * symbols: without a GPU they return Z_STREAM_ERROR.  A stream fed in pieces across several
- * calls is not supported (a second call reports Z_STREAM_END).  The only byte work on the host is
- * reading a private container's length field(s) so that the batch entry carries the exact size.
+ * symbols: without a GPU they return Z_STREAM_ERROR.  The only byte work on the host is framing:
+ * zlib / gzip headers and trailers, and reading a container's length field(s) so that the batch
+ * entry carries the exact size.
  *
- * inflate() follows the reference in what a one-call user can see: windowBits selects raw /
- * zlib / gzip / auto-detected framing and the header is skipped the way the reference skips it
- * (ref deflate-dec.inc.c:361-443, :452-477, :555-584; trailers are not checked there either,
- * SURVEY F13); at Z_STREAM_END total_in counts exactly the bytes the reference's bit reader
- * would have loaded (the kernels report the bit position behind the final end-of-block code);
- * a stream that produces more than avail_out returns Z_OK with the buffer FULL, input consumed
- * up to and including the token that did not fit (ref :521-545, :693-760, :805-830).
+ * inflate() follows the reference in what a caller can see: windowBits selects raw / zlib / gzip /
+ * auto-detected framing and the header is skipped the way the reference skips it (ref
+ * deflate-dec.inc.c:361-443, :452-477, :555-584); at Z_STREAM_END total_in counts exactly the bytes
+ * the reference's bit reader would have loaded (the kernels report the bit position behind the
+ * final end-of-block code); a stream that produces more than avail_out returns Z_OK with the
+ * buffer FULL (ref :521-545, :693-760, :805-830), the next call with no room returns Z_BUF_ERROR,
+ * and once the caller has made room (the reference's own CLI doubles its buffer, src/main.c:612-650)
+ * the stream goes on where the output stopped.  The batch decoder has no resumable state, so "goes
+ * on" is: the stream is decoded again from its first byte into a buffer that holds everything
+ * produced so far plus the new room, and the new part is handed out.  That needs the caller's input
+ * buffer to stay in place between the calls, which it does in every caller of the reference.
+ *
+ * Beyond the reference (documented extensions):
+ *  - inflate verifies a zlib (Adler-32) or gzip (CRC-32, ISIZE) trailer when the input holds it, and
+ *    counts it in total_in; a wrong trailer is Z_DATA_ERROR.  The reference never reads trailers.
+ *  - deflateInit2 honours windowBits like zlib: -8..-15 raw, 8..15 zlib framing, 24..31 gzip framing
+ *    (the reference refuses everything above 15, deflate-enc.inc.c:207-211, which is why its own
+ *    CLI's -g always fails).  The checksums are taken on the device.
  *
  * Differences from the reference that a caller can observe:
- *  - the call after such a Z_OK cannot resume the pending copy: it returns Z_OK again without
- *    progress (streaming across calls is not supported; the reference's callers never do it
- *    for archive entries, ref otezip.c:503-522);
  *  - on an error return (Z_DATA_ERROR, Z_BUF_ERROR) nothing is consumed and nothing written;
+ *  - a stream fed in pieces (input arriving across calls) is not supported: the first call needs the
+ *    whole compressed stream;
  *  - inflate: parity rules of DESIGN.md apply (the reference's premature Z_BUF_ERROR on
  *    some valid streams is repaired; malformed input fails cleanly);
  *  - deflate: the level is ignored and the output is VALID DEFLATE, dynamic-Huffman blocks (the
  *    reference's is not valid); only sizes are comparable;
  *  - zstdCompress finishes in one call (the reference wants to be called until it stops
- *    returning Z_OK, ref otezip.c:878-881); the bytes are the same.
+ *    returning Z_OK, ref otezip.c:878-881); the bytes are the same;
+ *  - zstdDecompress also accepts Zstandard frames per RFC 8878 that carry their content size.
  * The container writers are byte-exact, including the reference encoder's own magic byte order
  * for method 93 (which its decoder rejects). */
 #include <stdlib.h>
@@ -52,7 +63,12 @@ struct ozs_state {
 	int method;
 	int wrap;        /* inflate: framing selected by windowBits */
 	int header_done;
-	int stalled;     /* inflate returned Z_OK with a full buffer: cannot be resumed */
+	int wrap_seen;   /* inflate, after the header: OZS_WRAP_ZLIB / _GZIP / _NONE (what AUTO turned out to be) */
+	int stalled;     /* inflate returned Z_OK with a full buffer: the next call with room decodes again */
+	const unsigned char *in0; /* inflate: first byte of the DEFLATE stream (behind the header) */
+	uLong in0_len;            /* bytes the caller had from there on */
+	uLong in0_used;           /* of those, what next_in has been advanced over */
+	uLong out_made;           /* output bytes handed out since in0 */
 };
 
 static int ozs_device(void) {
@@ -213,6 +229,51 @@ static long long ozs_container_len(int method, const unsigned char *p, uInt n) {
 	return -1;
 }
 
+/* a Zstandard frame's content size, when the header carries it (RFC 8878 3.1.1.1); -1 otherwise */
+static long long ozs_zstd_content_size(const unsigned char *p, uInt n) {
+	if (n < 6 || p[0] != 0x28 || p[1] != 0xB5 || p[2] != 0x2F || p[3] != 0xFD || (p[4] & 0x18)) {
+		return -1; /* (bit 4 set: the reference's private framing; bit 3: reserved) */
+	}
+	const unsigned fhd = p[4], single = (fhd >> 5) & 1u, flag = fhd >> 6, did = fhd & 3u;
+	uInt at = 5 + (single ? 0u : 1u) + (did == 3u ? 4u : did);
+	const unsigned len = flag == 0 ? single : flag == 1 ? 2u : flag == 2 ? 4u : 8u;
+	if (len == 0 || at + len > n) {
+		return -1;
+	}
+	unsigned long long v = 0;
+	for (unsigned k = 0; k < len; k++) {
+		v |= (unsigned long long)p[at + k] << (8 * k);
+	}
+	if (len == 2) {
+		v += 256;
+	}
+	return v > 0x7FFFFFFFull ? -1 : (long long)v;
+}
+
+/* the trailer behind a framed DEFLATE stream, if the input holds it: 0 absent, > 0 its length (verified), -1 wrong */
+static int ozs_check_trailer(const struct ozs_state *st, const unsigned char *t, uLong avail, const unsigned char *out, uLong n, uint32_t crc) {
+	if (st->wrap_seen == OZS_WRAP_GZIP) {
+		if (avail < 8) {
+			return 0; /* truncated: the reference never looks */
+		}
+		const uint32_t want = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+		const uint32_t isize = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+		return want == crc && isize == (uint32_t)n ? 8 : -1;
+	}
+	if (st->wrap_seen == OZS_WRAP_ZLIB) {
+		if (avail < 4) {
+			return 0;
+		}
+		uint32_t ad = 0;
+		if (ozg_checksum_host (1, out, n, &ad) != OZG_OK) {
+			return -1;
+		}
+		const uint32_t want = ((uint32_t)t[0] << 24) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 8) | (uint32_t)t[3];
+		return want == ad ? 4 : -1;
+	}
+	return 0;
+}
+
 static int ozs_decode(z_stream *strm) {
 	if (!strm || !strm->state || !strm->next_out || (!strm->next_in && strm->avail_in)) {
 		return Z_STREAM_ERROR;
@@ -224,34 +285,54 @@ static int ozs_decode(z_stream *strm) {
 	if (st->finished) {
 		return Z_STREAM_END;
 	}
-	if (st->stalled) {
-		return Z_OK; /* the buffer was filled by the previous call; the pending rest cannot be resumed here */
+	if (st->stalled && strm->avail_out == 0) {
+		return Z_BUF_ERROR; /* no room, no progress (ref: the caller grows its buffer and calls again, main.c:612-650) */
 	}
-	if (st->method == OZG_METHOD_DEFLATE && !st->header_done && st->wrap != OZS_WRAP_NONE) {
+	if (st->method == OZG_METHOD_DEFLATE && !st->header_done) {
 		/* ref deflate-dec.inc.c:555-584 */
-		int skip;
-		if (st->wrap == OZS_WRAP_GZIP || (st->wrap == OZS_WRAP_AUTO && strm->avail_in >= 2 && strm->next_in[0] == 0x1f && strm->next_in[1] == 0x8b)) {
-			skip = ozs_skip_gzip (strm->next_in, strm->avail_in);
-		} else {
-			skip = ozs_skip_zlib (strm->next_in, strm->avail_in);
-		}
-		if (skip < 0) {
-			return Z_DATA_ERROR;
+		int skip = 0;
+		st->wrap_seen = OZS_WRAP_NONE;
+		if (st->wrap != OZS_WRAP_NONE) {
+			if (st->wrap == OZS_WRAP_GZIP || (st->wrap == OZS_WRAP_AUTO && strm->avail_in >= 2 && strm->next_in[0] == 0x1f && strm->next_in[1] == 0x8b)) {
+				skip = ozs_skip_gzip (strm->next_in, strm->avail_in);
+				st->wrap_seen = OZS_WRAP_GZIP;
+			} else {
+				skip = ozs_skip_zlib (strm->next_in, strm->avail_in);
+				st->wrap_seen = OZS_WRAP_ZLIB;
+			}
+			if (skip < 0) {
+				return Z_DATA_ERROR;
+			}
 		}
 		strm->next_in += skip;
 		strm->avail_in -= (uInt)skip;
 		strm->total_in += (uLong)skip;
 		st->header_done = 1;
 	}
+	if (!st->in0) {
+		st->in0 = strm->next_in;
+		st->in0_len = strm->avail_in;
+		st->in0_used = 0;
+		st->out_made = 0;
+	}
 	if (ozg_init (ozs_device ()) != OZG_OK) {
 		strm->msg = ozg_last_error ();
 		return Z_STREAM_ERROR;
 	}
-	uInt want = strm->avail_out;
+	/* the stream is decoded from its first byte: everything handed out so far, plus the room there is now */
+	const unsigned char *in = st->in0;
+	const uLong in_len = st->in0_len;
+	if (in_len > 0xFFFFFFFFul || st->out_made + (uLong)strm->avail_out > 0xFFFFFFF0ul) {
+		return Z_MEM_ERROR;
+	}
+	uInt want = (uInt) (st->out_made + strm->avail_out);
 	/* (method 14 needs no look-ahead: its token reader stops by itself and the batch kernel
 	 * reports what it wrote even when that is not the size the entry announced) */
 	if (st->method != OZG_METHOD_DEFLATE && st->method != OZG_METHOD_LZMA) {
-		long long plen = ozs_container_len (st->method, strm->next_in, strm->avail_in);
+		long long plen = st->method == OZG_METHOD_ZSTD ? ozs_zstd_content_size (in, (uInt)in_len) : -1;
+		if (plen < 0) {
+			plen = ozs_container_len (st->method, in, (uInt)in_len);
+		}
 		if (plen >= 0) {
 			if ((unsigned long long)plen > strm->avail_out) {
 				return Z_BUF_ERROR; /* the payload does not fit the caller's buffer */
@@ -261,7 +342,7 @@ static int ozs_decode(z_stream *strm) {
 	}
 	ozg_entry e;
 	memset (&e, 0, sizeof (e));
-	e.comp_size = strm->avail_in;
+	e.comp_size = (uint32_t)in_len;
 	e.uncomp_size = want;
 	e.method = (uint16_t)st->method;
 	e.flags = OZG_EF_IGNORE_ZIPBOMB; /* the ratio guard belongs to the archive reader (ref otezip.c:454-462) */
@@ -274,33 +355,55 @@ static int ozs_decode(z_stream *strm) {
 		return Z_MEM_ERROR;
 	}
 	uint64_t end_bit = 0;
-	int rc = ozg_decode_batch_host_ex (strm->avail_in ? strm->next_in : &dummy, strm->avail_in, out, out_len, &e, &r, 1, &end_bit);
+	int rc = ozg_decode_batch_host_ex (in_len ? in : &dummy, in_len, out, out_len, &e, &r, 1, &end_bit);
 	if (rc != OZG_OK) {
 		free (out);
 		strm->msg = ozg_last_error ();
 		return rc == OZG_E_NOMEM ? Z_MEM_ERROR : Z_STREAM_ERROR;
 	}
 	/* input the codec consumed: for DEFLATE the bytes the reference's bit reader would have loaded */
-	uInt used = strm->avail_in;
+	uLong used = in_len;
 	if (st->method == OZG_METHOD_DEFLATE) {
 		const uint64_t bytes = (end_bit + 7u) >> 3;
-		used = bytes < strm->avail_in ? (uInt)bytes : strm->avail_in;
+		used = bytes < in_len ? (uLong)bytes : in_len;
 	}
+	/* what this call adds: the caller's next_in sits in0_used bytes into the stream, out_made bytes are out */
+	const uLong in_step = used > st->in0_used ? used - st->in0_used : 0;
 	int ret;
 	switch (r.status) {
-	case OZG_ST_OK:
+	case OZG_ST_OK: {
 		/* end of the stream; a short DEFLATE stream leaves the rest of the buffer untouched */
-		memcpy (strm->next_out, out, r.total_out);
-		ozs_advance (strm, used, r.total_out);
+		int tl = 0;
+		if (st->method == OZG_METHOD_DEFLATE) {
+			uint32_t crc = r.crc32;
+			if (st->wrap_seen == OZS_WRAP_GZIP && r.total_out != want && in_len - used >= 8 &&
+				ozg_checksum_host (0, out, r.total_out, &crc) != OZG_OK) {
+				/* (a stream shorter than the buffer: the kernel's CRC covers the zero-filled rest too) */
+				ret = Z_STREAM_ERROR;
+				break;
+			}
+			tl = ozs_check_trailer (st, in + used, in_len - used, out, r.total_out, crc);
+			if (tl < 0) {
+				ret = Z_DATA_ERROR;
+				break;
+			}
+		}
+		const uLong fresh = r.total_out > st->out_made ? r.total_out - st->out_made : 0;
+		memcpy (strm->next_out, out + st->out_made, fresh);
+		ozs_advance (strm, (uInt) (in_step + (uLong)tl), (uInt)fresh);
 		st->finished = 1;
 		ret = Z_STREAM_END;
 		break;
+	}
 	case OZG_ST_NEED_OUT:
 		if (st->method == OZG_METHOD_DEFLATE) {
-			/* the stream wants more than avail_out bytes: buffer full, Z_OK (ref :805-830) */
-			memcpy (strm->next_out, out, r.total_out);
-			ozs_advance (strm, used, r.total_out);
-			st->stalled = strm->avail_in != 0 || r.total_out != 0;
+			/* the stream wants more than there is room for: buffer full, Z_OK (ref :805-830) */
+			const uLong fresh = r.total_out > st->out_made ? r.total_out - st->out_made : 0;
+			memcpy (strm->next_out, out + st->out_made, fresh);
+			ozs_advance (strm, (uInt)in_step, (uInt)fresh);
+			st->in0_used += in_step;
+			st->out_made += fresh;
+			st->stalled = 1;
 			ret = Z_OK;
 			break;
 		}
@@ -339,13 +442,28 @@ int inflate(z_stream *strm, int flush) {
 
 int deflateInit2(z_stream *strm, int level, int method, int windowBits, int memLevel, int strategy) {
 	(void)level; /* the reference's caller always ends up at its default level (ref otezip.c:826) */
-	(void)windowBits;
 	(void)memLevel;
 	(void)strategy;
 	if (method != 8) {
 		return Z_STREAM_ERROR;
 	}
-	return ozs_init (strm, 0, OZG_METHOD_DEFLATE);
+	/* zlib's convention (the reference accepts -8..-15 and 8..15 and writes raw DEFLATE for both,
+	 * ref deflate-enc.inc.c:207-215; +16 = gzip is what its CLI asks for, src/main.c:676) */
+	int wrap;
+	if (windowBits >= -15 && windowBits <= -8) {
+		wrap = OZS_WRAP_NONE;
+	} else if (windowBits >= 8 && windowBits <= 15) {
+		wrap = OZS_WRAP_ZLIB;
+	} else if (windowBits >= 24 && windowBits <= 31) {
+		wrap = OZS_WRAP_GZIP;
+	} else {
+		return Z_STREAM_ERROR;
+	}
+	int rc = ozs_init (strm, 0, OZG_METHOD_DEFLATE);
+	if (rc == Z_OK) {
+		((struct ozs_state *)strm->state)->wrap = wrap;
+	}
+	return rc;
 }
 
 int deflateInit2_(z_stream *strm, int level, int method, int windowBits, int memLevel, int strategy, const char *version, int stream_size) {
@@ -373,16 +491,23 @@ static int ozs_encode(z_stream *strm) {
 		strm->msg = ozg_last_error ();
 		return Z_STREAM_ERROR;
 	}
+	/* framing of the DEFLATE seam (RFC 1950 / RFC 1952): header, raw stream, trailer */
+	const int wrap = st->method == OZG_METHOD_DEFLATE ? st->wrap : OZS_WRAP_NONE;
+	const uInt head = wrap == OZS_WRAP_GZIP ? 10u : wrap == OZS_WRAP_ZLIB ? 2u : 0u;
+	const uInt tail = wrap == OZS_WRAP_GZIP ? 8u : wrap == OZS_WRAP_ZLIB ? 4u : 0u;
+	if (strm->avail_out < head + tail) {
+		return Z_BUF_ERROR;
+	}
 	ozg_enc_entry e;
 	memset (&e, 0, sizeof (e));
 	e.src_size = strm->avail_in;
-	e.dst_cap = strm->avail_out;
+	e.dst_cap = strm->avail_out - head - tail;
 	e.method = (uint16_t)st->method;
-	e.reserved = OZG_ENC_F_CODEC_ONLY;
+	e.reserved = OZG_ENC_F_CODEC_ONLY | (wrap == OZS_WRAP_ZLIB ? OZG_ENC_F_ADLER32 : 0u);
 	ozg_enc_result r;
 	memset (&r, 0, sizeof (r));
 	const unsigned char dummy = 0;
-	uint64_t out_len = ((uint64_t)strm->avail_out + 15u) & ~(uint64_t)15u;
+	uint64_t out_len = ((uint64_t)e.dst_cap + 15u) & ~(uint64_t)15u;
 	unsigned char *out = (unsigned char *)malloc (out_len ? out_len : 16);
 	if (!out) {
 		return Z_MEM_ERROR;
@@ -395,9 +520,29 @@ static int ozs_encode(z_stream *strm) {
 	}
 	int ret;
 	if (r.status == OZG_ST_OK) {
-		memcpy (strm->next_out, out, r.comp_size);
-		ozs_advance (strm, strm->avail_in, r.comp_size);
-		strm->adler = r.crc32; /* CRC-32 of the input, as the zip writer needs it */
+		unsigned char *o = strm->next_out;
+		const uInt n_in = strm->avail_in;
+		if (wrap == OZS_WRAP_GZIP) {
+			static const unsigned char gz[10] = { 0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 0xff }; /* no name, no time, unknown OS */
+			memcpy (o, gz, 10);
+		} else if (wrap == OZS_WRAP_ZLIB) {
+			o[0] = 0x78; /* deflate, 32 KiB window */
+			o[1] = 0x9c; /* default level; makes the pair a multiple of 31 */
+		}
+		memcpy (o + head, out, r.comp_size);
+		unsigned char *t = o + head + r.comp_size;
+		if (wrap == OZS_WRAP_GZIP) {
+			for (int k = 0; k < 4; k++) {
+				t[k] = (unsigned char) (r.crc32 >> (8 * k));
+				t[4 + k] = (unsigned char) ((uint32_t)n_in >> (8 * k));
+			}
+		} else if (wrap == OZS_WRAP_ZLIB) {
+			for (int k = 0; k < 4; k++) {
+				t[k] = (unsigned char) (r.crc32 >> (8 * (3 - k))); /* (the Adler-32 of the input: OZG_ENC_F_ADLER32) */
+			}
+		}
+		ozs_advance (strm, strm->avail_in, head + r.comp_size + tail);
+		strm->adler = r.crc32; /* CRC-32 (Adler-32 for the zlib framing) of the input, as zlib reports it */
 		st->finished = 1;
 		ret = Z_STREAM_END;
 	} else {

@@ -75,3 +75,33 @@ def test_reference_cli_creates_an_archive_other_readers_accept(tmp_path):
         for n, d in files.items():
             assert z.read(n) == d
         assert z.getinfo("a.txt").compress_type == zipfile.ZIP_DEFLATED
+
+
+@pytest.mark.gpu
+def test_reference_cli_gzip_and_gunzip(tmp_path):
+    """`mzip -g file` and `mzip -d file.gz` (ref src/main.c:590-832).  With the reference's own library -g always
+    fails (deflateInit2 refuses windowBits 31); here it writes a gzip member the system's gzip
+    accepts, and -d reads what the system's gzip wrote -- including a member that expands far beyond the
+    4 x its CLI first allocates, so that its grow-and-call-again loop (main.c:612-650) runs."""
+    import shutil
+    if not os.path.exists(CLI):
+        pytest.fail("oracle/_ref/otezip_cli_amd did not travel with the snapshot")
+    if not shutil.which("gzip"):
+        pytest.skip("no system gzip")
+    from otezip_amd import corpus
+    text = corpus.gen_text(12, 300000)
+    sparse = (corpus.gen_text(13, 3000) * 50) + bytes(400000)  # expands ~40 x
+    for name, data in (("t.txt", text), ("s.bin", sparse), ("tiny", b"x")):
+        src = tmp_path / name
+        src.write_bytes(data)
+        p = subprocess.run([CLI, "-g", str(src), str(src) + ".gz"], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, (p.stdout, p.stderr)
+        assert subprocess.run(["gzip", "-t", str(src) + ".gz"], capture_output=True).returncode == 0
+        assert subprocess.run(["gzip", "-dc", str(src) + ".gz"], capture_output=True).stdout == data
+        # the other way round: the system's gzip writes, the reference's CLI on this library reads
+        sysgz = tmp_path / (name + ".sys.gz")
+        sysgz.write_bytes(subprocess.run(["gzip", "-c", str(src)], capture_output=True).stdout)
+        out = tmp_path / (name + ".back")
+        p = subprocess.run([CLI, "-d", str(sysgz), str(out)], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, (p.stdout, p.stderr)
+        assert out.read_bytes() == data

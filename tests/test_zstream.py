@@ -96,7 +96,8 @@ def test_inflate_matches_the_oracle(gpu_lib):
 @pytest.mark.gpu
 def test_inflate_honours_window_bits_like_the_reference(gpu_lib):
     """zlib / gzip / auto-detected framing (ref deflate-dec.inc.c:452-477, :555-584): the header is
-    skipped, the trailer is left unread, total_in says so."""
+    skipped; the trailer, which the reference leaves unread, is verified when the input
+    holds it and counted in total_in (documented extension)."""
     import gzip
     L = gpu_lib.lib()
     data = cases.word_text(__import__("random").Random(5), 30000)
@@ -105,11 +106,19 @@ def test_inflate_honours_window_bits_like_the_reference(gpu_lib):
     gz = gzip.compress(data, 6, mtime=0)
     co = zlib.compressobj(6, zlib.DEFLATED, 31)
     gz_named = b"\x1f\x8b\x08\x18" + b"\0" * 6 + b"name.txt\0" + b"a comment\0" + co.compress(data)[10:] + co.flush()
-    for wbits, blob, hdr in ((15, zl, 2), (31, gz, 10), (47, gz, 10), (47, zl, 2), (31, gz_named, 10 + 9 + 10), (-15, raw, 0)):
+    for wbits, blob, hdr, trl in ((15, zl, 2, 4), (31, gz, 10, 8), (47, gz, 10, 8), (47, zl, 2, 4), (31, gz_named, 10 + 9 + 10, 8), (-15, raw, 0, 0)):
         ret, tin, tout, left, out, again = gpu_inflate(L, blob, len(data) + 10, wbits)
         assert ret == 1 and out[:tout] == data and tout == len(data), (wbits, ret)
         r, _ = O.codec_decode(8, blob[hdr:], len(data) + 10)
-        assert tin == hdr + r.total_in, (wbits, tin, hdr, r.total_in)
+        assert tin == hdr + r.total_in + trl == len(blob), (wbits, tin, hdr, r.total_in)
+        if trl:
+            # a trailer cut short is not looked at (as in the reference); a wrong one is a data error
+            ret, tin, tout, _, out, _ = gpu_inflate(L, blob[:-2], len(data) + 10, wbits)
+            assert ret == 1 and out[:tout] == data and tin == hdr + r.total_in
+            for k in (1, trl):
+                bad = bytearray(blob)
+                bad[-k] ^= 0x20
+                assert gpu_inflate(L, bytes(bad), len(data) + 10, wbits)[0] == -3, (wbits, k)
     # the wrong framing is a data error, as in the reference
     for wbits, blob in ((31, zl), (15, gz), (47, b"\x00\x01junk")):
         assert gpu_inflate(L, blob, 100, wbits)[0] == -3
@@ -219,3 +228,77 @@ def test_container_readers_match_the_reference(gpu_lib):
     back = C.create_string_buffer(len(d))
     assert L.lzfse_decompress(comp, n, back, len(back)) == len(d) and back.raw == d
     assert L.lzfse_decompress(comp, n, back, 10) == 0
+
+
+@pytest.mark.gpu
+def test_deflate_frames_like_zlib_for_every_window_bits(gpu_lib):
+    """deflateInit2 honours windowBits the way zlib does (the reference refuses > 15, which is why its own
+    CLI's -g fails): raw, zlib framing with the Adler-32 taken on the device, gzip framing with
+    CRC-32 and ISIZE.  Python's zlib / gzip read all three."""
+    import gzip
+    from otezip_amd import corpus
+    L = gpu_lib.lib()
+    for data in (b"", b"a", corpus.gen_text(3, 70000), bytes(range(256)) * 300, b"\xff" * 5000):
+        for wbits in (-15, 15, 9, 31, 25):
+            s, inb, out = _stream(data, len(data) + len(data) // 8 + 200)
+            assert L.deflateInit2(C.byref(s), 6, 8, wbits, 8, 0) == 0
+            assert L.deflate(C.byref(s), Z_FINISH) == 1
+            blob = out.raw[:s.total_out]
+            assert s.total_in == len(data)
+            assert L.deflateEnd(C.byref(s)) == 0
+            if wbits < 0:
+                assert zlib.decompress(blob, -15) == data
+            elif wbits < 16:
+                assert zlib.decompress(blob) == data and s.adler == zlib.adler32(data)
+            else:
+                assert gzip.decompress(blob) == data and s.adler == zlib.crc32(data)
+    s, inb, out = _stream(b"x", 64)
+    for bad in (0, 7, 16, 23, 32, 47, -7, -16):
+        assert L.deflateInit2(C.byref(s), 6, 8, bad, 8, 0) == -2, bad
+    # no room for the framing itself
+    s, inb, out = _stream(b"x" * 100, 9)
+    assert L.deflateInit2(C.byref(s), 6, 8, 31, 8, 0) == 0 and L.deflate(C.byref(s), Z_FINISH) == -5
+    L.deflateEnd(C.byref(s))
+
+
+@pytest.mark.gpu
+def test_inflate_goes_on_when_the_caller_makes_room(gpu_lib):
+    """The protocol of the reference's own CLI (src/main.c:612-650): Z_OK with the buffer full, Z_BUF_ERROR
+    while there is no room, and after the caller has grown its buffer the stream goes on -- here until a
+    gzip member that expands 16 x has been read through a buffer that starts at a twentieth of its size."""
+    import gzip
+    from otezip_amd import corpus
+    L = gpu_lib.lib()
+    data = (corpus.gen_text(9, 4000) * 40) + bytes(70000) + corpus.gen_text(10, 30000)
+    blob = gzip.compress(data, 6, mtime=0)
+    assert len(data) > 10 * len(blob)
+    inb = C.create_string_buffer(blob, len(blob))
+    alloc = len(data) // 20
+    buf = C.create_string_buffer(alloc)
+    s = O.ZStream()
+    s.next_in = C.cast(inb, C.c_void_p)
+    s.avail_in = len(blob)
+    s.next_out = C.cast(buf, C.c_void_p)
+    s.avail_out = alloc
+    assert L.inflateInit2(C.byref(s), 15 + 32) == 0
+    calls = {0: 0, 1: 0, -5: 0}
+    got = b""
+    for _ in range(200):
+        ret = L.inflate(C.byref(s), 0)
+        calls[ret] = calls.get(ret, 0) + 1
+        if ret == 1:
+            break
+        if ret == -5:
+            assert s.avail_out == 0
+            produced = s.total_out
+            got = buf.raw[:produced]  # (what realloc would carry over)
+            alloc *= 2
+            buf = C.create_string_buffer(got, alloc)
+            s.next_out = C.cast(C.addressof(buf) + produced, C.c_void_p)
+            s.avail_out = alloc - produced
+            continue
+        assert ret == 0 and s.avail_out == 0, ret
+    assert ret == 1 and s.total_out == len(data) and buf.raw[:len(data)] == data
+    assert s.total_in == len(blob) and s.avail_in == 0
+    assert calls[0] >= 3 and calls[-5] >= 3
+    assert L.inflateEnd(C.byref(s)) == 0
