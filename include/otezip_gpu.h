@@ -120,6 +120,8 @@ int ozg_decode_batch_device(const void *d_src, uint64_t src_len, void *d_dst, ui
  * the caller (who parsed the central directory) knows it is not needed. */
 #define OZG_BATCH_ONLY_DEFLATE 1u /* every entry is method 8: skip the copy kernel */
 #define OZG_BATCH_NO_DEFLATE 2u   /* no entry is method 8: skip the inflate kernel */
+#define OZG_BATCH_NO_LZMA 8u      /* no entry is method 14: skip the LZMA1 kernel (a method-14 payload is sniffed: an LZMA1
+                                   * stream behind the APPNOTE 5.8.8 header, or the reference's private token format) */
 #define OZG_BATCH_NO_ZSTD 4u      /* no entry is method 93: skip the Zstandard kernels (a method-93 payload is sniffed:
                                    * a Zstandard frame per RFC 8878, or the reference's private raw-block framing) */
 int ozg_decode_batch_device_ex(const void *d_src, uint64_t src_len, void *d_dst, uint64_t dst_len,

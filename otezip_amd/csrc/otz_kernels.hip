@@ -30,6 +30,7 @@
 #include "otz_dispatch.h"
 #include "otz_deflate_enc.h"
 #include "otz_zstd.h"
+#include "otz_lzma.h"
 
 static_assert (sizeof (ozg_entry) == 32, "ozg_entry ABI");
 static_assert (sizeof (ozg_result) == 16, "ozg_result ABI");
@@ -195,7 +196,28 @@ otz_zstd_prof_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_resul
 	otz_zstd_grid<true> (src, dst, entries, results, n, src_len, dst_len, lim, lit_scratch, cursor, route, prof);
 }
 
-// CRC-32 of the entries otz_zstd_kernel decoded (ref src/lib/otezip.c:667-679)
+// LZMA1 streams under method 14 (otz_lzma.h): one WORK-ITEM per entry -- an LZMA stream has no
+// parallelism inside, the batch has one stream per entry.  A persistent grid: every work-item takes
+// the next entry off a counter and owns OTZ_LZMA_PROB_BYTES of scratch for its probability model.
+extern "C" __global__ void __launch_bounds__ (64)
+otz_lzma_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *results, u32 n, u64 src_len, u64 dst_len, ozg_limits lim,
+	u8 *prob_scratch, u32 *cursor, u8 *route) {
+	u16 *probs = reinterpret_cast<u16 *> (prob_scratch + (size_t) (blockIdx.x * 64u + threadIdx.x) * OTZ_LZMA_PROB_BYTES);
+	for (;;) {
+		const u32 i = atomicAdd (cursor, 1u);
+		if (i >= n) {
+			break;
+		}
+		const ozg_entry e = entries[i];
+		if (e.method != OZG_METHOD_LZMA || !otz_entry_in_bounds (e, src_len, dst_len) || otz_zipbomb (e, lim) ||
+			!otz_lzma_is_candidate (src + e.src_off, e.comp_size)) {
+			continue; // the copy kernel's (route stays 0)
+		}
+		otz_lzma_run (src + e.src_off, e.comp_size, dst + e.dst_off, e.uncomp_size, probs, &results[i], &route[i]);
+	}
+}
+
+// CRC-32 of the entries otz_zstd_kernel / otz_lzma_kernel decoded (ref src/lib/otezip.c:667-679)
 extern "C" __global__ void __launch_bounds__ (256)
 otz_zstd_crc_kernel(u8 *dst, const ozg_entry *entries, ozg_result *results, u32 n, const u8 *route) {
 	extern __shared__ __attribute__ ((aligned (16))) u8 otz_smem[];
@@ -494,6 +516,10 @@ struct workspace {
 	u32 *zs_cursor = nullptr;
 	u8 *zs_route = nullptr;
 	size_t zs_route_cap = 0;
+	// LZMA1: probability-model scratch of the persistent grid
+	u8 *lz_probs = nullptr;
+	u32 lz_threads = 0;
+	u32 *lz_cursor = nullptr;
 	// encode side: token scratch of the persistent grid, its buffer counter
 	u32 *enc_tok = nullptr;
 	u32 enc_grid = 0;
@@ -656,6 +682,8 @@ void ws_free(workspace &ws) {
 	(void)hipFree (ws.zs_lit);
 	(void)hipFree (ws.zs_cursor);
 	(void)hipFree (ws.zs_route);
+	(void)hipFree (ws.lz_probs);
+	(void)hipFree (ws.lz_cursor);
 	if (ws.enc_done) {
 		(void)hipEventDestroy (ws.enc_done);
 	}
@@ -739,28 +767,39 @@ int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, 
 	}
 	if (!(batch_flags & OZG_BATCH_ONLY_DEFLATE)) {
 		const u8 *route = nullptr;
-		if (!(batch_flags & OZG_BATCH_NO_ZSTD)) {
-			// method 93: Zstandard frames first (the rest of the batch, and what turns out not to be
-			// Zstandard, is the copy kernel's)
+		const bool want_zs = !(batch_flags & OZG_BATCH_NO_ZSTD), want_lz = !(batch_flags & OZG_BATCH_NO_LZMA);
+		if (want_zs || want_lz) {
+			// methods 93 and 14: the real formats first (the rest of the batch, and what turns out not to
+			// be one of them, is the copy kernel's)
 			workspace &ws = C.ws;
 			const u32 grid = n < C.zs_grid ? n : C.zs_grid;
+			const u32 lz_threads = ((n < 32768u ? n : 32768u) + 63u) & ~63u;
 			if (!ws.done) {
 				OZG_HIP (hipEventCreateWithFlags (&ws.done, hipEventDisableTiming));
 			}
 			if (!ws.zs_cursor) {
 				OZG_HIP (hipMalloc ((void **)&ws.zs_cursor, 256));
+				OZG_HIP (hipMalloc ((void **)&ws.lz_cursor, 256));
 			}
-			if (grid > ws.zs_grid || n > ws.zs_route_cap) {
+			if ((want_zs && grid > ws.zs_grid) || n > ws.zs_route_cap || (want_lz && lz_threads > ws.lz_threads)) {
 				OZG_HIP (hipDeviceSynchronize ()); // an earlier batch may still use what is about to be freed
 				ws.busy = false;
 			}
-			if (grid > ws.zs_grid) {
+			if (want_zs && grid > ws.zs_grid) {
 				(void)hipFree (ws.zs_lit);
 				ws.zs_lit = nullptr;
 				ws.zs_grid = 0;
 				const u32 g = grid < 64u ? 64u : (grid + (grid >> 1) < C.zs_grid ? grid + (grid >> 1) : C.zs_grid);
 				OZG_HIP (hipMalloc ((void **)&ws.zs_lit, (size_t)g * OTZ_ZS_LIT_BYTES));
 				ws.zs_grid = g;
+			}
+			if (want_lz && lz_threads > ws.lz_threads) {
+				(void)hipFree (ws.lz_probs);
+				ws.lz_probs = nullptr;
+				ws.lz_threads = 0;
+				const u32 t = lz_threads < 1024u ? 1024u : (lz_threads + (lz_threads >> 1) < 32768u ? (lz_threads + (lz_threads >> 1) + 63u) & ~63u : 32768u);
+				OZG_HIP (hipMalloc ((void **)&ws.lz_probs, (size_t)t * OTZ_LZMA_PROB_BYTES));
+				ws.lz_threads = t;
 			}
 			if (n > ws.zs_route_cap) {
 				(void)hipFree (ws.zs_route);
@@ -774,15 +813,23 @@ int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, 
 				OZG_HIP (hipStreamWaitEvent (s, ws.done, 0)); // the scratch is shared between streams
 			}
 			OZG_HIP (hipMemsetAsync (ws.zs_cursor, 0, 4, s));
+			OZG_HIP (hipMemsetAsync (ws.lz_cursor, 0, 4, s));
 			OZG_HIP (hipMemsetAsync (ws.zs_route, 0, n, s));
-			if (g_prof) {
-				hipLaunchKernelGGL (otz_zstd_prof_kernel, dim3 (grid), dim3 (64), sizeof (otz_zs_lds), s, (const u8 *)d_src, (u8 *)d_dst, d_entries, d_results, n,
-					(u64)src_len, (u64)dst_len, g_limits, ws.zs_lit, ws.zs_cursor, ws.zs_route, g_prof);
-			} else {
-				hipLaunchKernelGGL (otz_zstd_kernel, dim3 (grid), dim3 (64), sizeof (otz_zs_lds), s, (const u8 *)d_src, (u8 *)d_dst, d_entries, d_results, n,
-					(u64)src_len, (u64)dst_len, g_limits, ws.zs_lit, ws.zs_cursor, ws.zs_route);
+			if (want_zs) {
+				if (g_prof) {
+					hipLaunchKernelGGL (otz_zstd_prof_kernel, dim3 (grid), dim3 (64), sizeof (otz_zs_lds), s, (const u8 *)d_src, (u8 *)d_dst, d_entries, d_results, n,
+						(u64)src_len, (u64)dst_len, g_limits, ws.zs_lit, ws.zs_cursor, ws.zs_route, g_prof);
+				} else {
+					hipLaunchKernelGGL (otz_zstd_kernel, dim3 (grid), dim3 (64), sizeof (otz_zs_lds), s, (const u8 *)d_src, (u8 *)d_dst, d_entries, d_results, n,
+						(u64)src_len, (u64)dst_len, g_limits, ws.zs_lit, ws.zs_cursor, ws.zs_route);
+				}
+				OZG_HIP (hipGetLastError ());
 			}
-			OZG_HIP (hipGetLastError ());
+			if (want_lz) {
+				hipLaunchKernelGGL (otz_lzma_kernel, dim3 (lz_threads / 64u), dim3 (64), 0, s, (const u8 *)d_src, (u8 *)d_dst, d_entries, d_results, n,
+					(u64)src_len, (u64)dst_len, g_limits, ws.lz_probs, ws.lz_cursor, ws.zs_route);
+				OZG_HIP (hipGetLastError ());
+			}
 			route = ws.zs_route;
 		}
 		hipLaunchKernelGGL (otz_copy_kernel, dim3 (n), dim3 (256), sizeof (otz_copy_lds), s, (const u8 *)d_src,
@@ -800,7 +847,7 @@ int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, 
 
 // host-side view of a descriptor table: bounds, and which launches it needs
 int check_entries(const ozg_entry *entries, uint32_t n, uint64_t src_len, uint64_t dst_len, uint32_t *flags) {
-	uint32_t f = OZG_BATCH_NO_DEFLATE | OZG_BATCH_ONLY_DEFLATE | OZG_BATCH_NO_ZSTD;
+	uint32_t f = OZG_BATCH_NO_DEFLATE | OZG_BATCH_ONLY_DEFLATE | OZG_BATCH_NO_ZSTD | OZG_BATCH_NO_LZMA;
 	for (uint32_t i = 0; i < n; i++) {
 		const ozg_entry &e = entries[i];
 		if (e.src_off > src_len || e.comp_size > src_len - e.src_off || (e.dst_off & 15u) || e.dst_off > dst_len ||
@@ -811,6 +858,9 @@ int check_entries(const ozg_entry *entries, uint32_t n, uint64_t src_len, uint64
 		f &= e.method == OZG_METHOD_DEFLATE ? ~OZG_BATCH_NO_DEFLATE : ~OZG_BATCH_ONLY_DEFLATE;
 		if (e.method == OZG_METHOD_ZSTD) {
 			f &= ~OZG_BATCH_NO_ZSTD;
+		}
+		if (e.method == OZG_METHOD_LZMA) {
+			f &= ~OZG_BATCH_NO_LZMA;
 		}
 	}
 	*flags = f;

@@ -7,6 +7,7 @@
 #include "otz_huff_index.h"
 #include "otz_lz_apply.h"
 #include "otz_zstd.h"
+#include "otz_lzma.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -65,6 +66,12 @@ void *thread_main(void *p) {
 		const ozg_entry &e = *a->e;
 		if (!otz_zipbomb (e, a->lim) && otz_zs_is_candidate (a->src + e.src_off, e.comp_size)) {
 			otz_zs_run<false> (*(otz_zs_lds *)a->lds, a->src + e.src_off, e.comp_size, a->dst + e.dst_off, e.uncomp_size, a->zs_lit, a->r, a->zs_route);
+		}
+	} else if (a->phase == 6) {
+		// what otz_lzma_kernel does for one entry (one work-item)
+		const ozg_entry &e = *a->e;
+		if (otz_tid () == 0 && !otz_zipbomb (e, a->lim) && otz_lzma_is_candidate (a->src + e.src_off, e.comp_size)) {
+			otz_lzma_run (a->src + e.src_off, e.comp_size, a->dst + e.dst_off, e.uncomp_size, (u16 *)a->zs_lit, a->r, a->zs_route);
 		}
 	} else if (a->phase == 5) {
 		// what otz_zstd_crc_kernel does
@@ -251,6 +258,23 @@ extern "C" int emu_decode_batch_mode(const void *src, uint64_t src_len, void *ds
 			a.zs_route = &route;
 			a.phase = 4;
 			run_block (64, a, sizeof (otz_zs_lds));
+			a.phase = 0;
+			if (route != OTZ_ZS_ROUTE_DONE) {
+				run_block (OTZ_CNT, a, lds_bytes);
+			} else if (results[i].status == OZG_ST_OK) {
+				a.phase = 5;
+				run_block (OTZ_CNT, a, lds_bytes);
+			}
+			continue;
+		}
+		if (entries[i].method == OZG_METHOD_LZMA) {
+			// product order: LZMA1 kernel, copy kernel (private tokens) unless it decoded the entry, CRC pass
+			std::vector<u8> probs (OTZ_LZMA_PROB_BYTES, 0xA5);
+			u8 route = 0;
+			a.zs_lit = probs.data ();
+			a.zs_route = &route;
+			a.phase = 6;
+			run_block (64, a, 64);
 			a.phase = 0;
 			if (route != OTZ_ZS_ROUTE_DONE) {
 				run_block (OTZ_CNT, a, lds_bytes);
