@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """TEST INFRASTRUCTURE: writes tests/golden/zstd_frames.json -- Zstandard frames produced by the image's
-libzstd 1.4.8 (oracle/zstdlib.py), each with the SHA-256 of its content, and the list of format features
+libzstd 1.4.8 (tools/zstdlib.py), each with the SHA-256 of its content, and the list of format features
 every frame exercises (found by inspect_frame below, which parses block / literal / sequence headers).
 The fixtures pin oracle/otz_zstd_rfc.c and the GPU decoder on machines where no libzstd is present.
 
@@ -15,7 +15,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import zstdlib as Z  # noqa: E402
+from tools import zstdlib as Z  # noqa: E402
 from otezip_amd import corpus  # noqa: E402
 
 

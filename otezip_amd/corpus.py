@@ -207,24 +207,3 @@ def _text_buffers(n, size, first, workers):
             return pool.map(_text_one, jobs, chunksize=max(1, n // (workers * 8)))
     return [_text_one(j) for j in jobs]
 
-
-def _zstd_one(args):
-    idx, size, level = args
-    from oracle import zstdlib as Z  # test / measurement infrastructure: the image's libzstd makes the frames
-    data = gen_text(idx, size)
-    return idx, 93, Z.compress(data, level=level), len(data), zlib.crc32(data) & 0xFFFFFFFF
-
-
-def build_zstd_real(n, size, level=3, first=0, workers=None):
-    """An archive image of n method-93 entries holding REAL Zstandard frames (libzstd of the image, through
-    oracle/zstdlib.py -- only measurement tools and tests call this; the product never does)."""
-    def make():
-        jobs = [(first + i, size, level) for i in range(n)]
-        w = workers if workers is not None else min(mp.cpu_count(), 16)
-        if w > 1 and n >= 64:
-            with mp.get_context("fork").Pool(w) as pool:
-                made = pool.map(_zstd_one, jobs, chunksize=max(1, n // (w * 8)))
-        else:
-            made = [_zstd_one(j) for j in jobs]
-        return _serialise(made)
-    return _cached("zstdreal_v1_n%d_s%d_l%d_f%d" % (n, size, level, first), make, 1000, n)

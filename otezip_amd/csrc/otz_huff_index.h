@@ -39,12 +39,21 @@
 #ifndef OTZ_K1_WARM
 #define OTZ_K1_WARM 128u  // head start of walk A (bits)
 #endif
-#define OTZ_K1_SLOT (OTZ_K1_WARM / 8u + OTZ_K1_S / 8u + 12u) // slot bytes per lane: WARM/8 before + S/8 + 12 behind; 23 dwords (odd: no bank conflicts)
+#define OTZ_K1_SLOT (OTZ_K1_WARM / 8u + OTZ_K1_S / 8u + 12u) // bytes a lane may touch: WARM/8 before its segment + S/8 + 12 behind
+// The round's input sits in LDS ONCE, as one window: [segment of lane 0 - WARM/8 bytes, segment of lane 63
+// + 12 bytes).  A lane's warm-up stretch is its left neighbour's tail and its look-ahead its right
+// neighbour's head, so nothing is stored twice (private per-lane slots took 5.9 KB: with 4.4 KB here and
+// trimmed tables the wavefront fits 8 KB of LDS, i.e. five wavefronts per SIMD instead of four).
+// Lanes read at the same offset of their 16-word segments: one padding word after every 16 makes the
+// lane stride 17 words, which keeps those reads on different banks.
+#define OTZ_K1_WIN_BYTES (OTZ_K1_WARM / 8u + 64u * (OTZ_K1_S / 8u) + 16u) // 16 + 4096 + 16
+#define OTZ_K1_WIN_WORDS (OTZ_K1_WIN_BYTES / 4u)
+#define OTZ_K1_WIN_PADDED (OTZ_K1_WIN_WORDS + OTZ_K1_WIN_WORDS / 16u + 2u)
 #define OTZ_K1_NCAP (OTZ_K1_ROWS * OTZ_IX_G) // tokens a walk may take per round
 #define OTZ_K1_HDR_WORDS 264u // staged bytes for a block header: 17 + 57 + 318 x 14 bits < 1056 bytes
 
 static_assert (OTZ_K1_S % 8u == 0 && OTZ_K1_WARM % 8u == 0, "byte-granular slots");
-static_assert (OTZ_K1_SLOT % 4u == 0 && (OTZ_K1_SLOT / 4u) % 2u == 1u, "odd dword stride");
+static_assert (OTZ_K1_S == 512u && OTZ_K1_WARM == 128u, "a lane's segment is 16 words, its slot starts 4 words before it");
 static_assert (OTZ_K1_SLOT >= OTZ_K1_WARM / 8u + OTZ_K1_S / 8u + 9u, "a token starting on the segment's last bit must fit");
 static_assert ((OTZ_IX_G & (OTZ_IX_G - 1u)) == 0, "power of two");
 
@@ -73,18 +82,21 @@ static_assert ((OTZ_IX_G & (OTZ_IX_G - 1u)) == 0, "power of two");
 #define OTZ_K1_DBAD 0x3FFFu
 #define OTZ_K1_LROOT 10u
 #define OTZ_K1_DROOT 8u
+// Sub-table room: zlib's worst cases (ENOUGH: 1332 / 592 entries) need adversarial code sets; streams that
+// compressors write stay far below these sizes, and a block that does not fit sends its entry to the
+// self-contained kernel (OTZ_IX_OVERFLOW), so the sizes are a speed choice, never a correctness one.
 #ifndef OTZ_K1_LLUT
-#define OTZ_K1_LLUT 1344u // 1024 + 320 (zlib's ENOUGH for 286 symbols, root 10, 15 bits: 1332)
+#define OTZ_K1_LLUT 1216u // 1024 + 192
 #endif
 #ifndef OTZ_K1_DLUT
-#define OTZ_K1_DLUT 640u  // 256 + 384
+#define OTZ_K1_DLUT 384u  // 256 + 128
 #endif
 
 struct otz_k1_lds {
 	u16 lit[OTZ_K1_LLUT];
 	u16 dist[OTZ_K1_DLUT];
 	union {
-		u8 slots[64u * OTZ_K1_SLOT + 32u];
+		u32 win[OTZ_K1_WIN_PADDED];
 		struct { // block prologue only
 			u32 hdr_w[OTZ_K1_HDR_WORDS + 4u];
 			u32 cl_lut[128];
@@ -474,17 +486,25 @@ OTZ_DEV otz_k1_tok otz_k1_decode_bits(const otz_k1_lds &L, u32 lo, u32 hi) {
 	return t;
 }
 
-// three dword-aligned slot words and a funnel shift (a byte-unaligned 8-byte LDS read costs 5x the LDS time)
-OTZ_DEV otz_k1_tok otz_k1_decode(const otz_k1_lds &L, const u8 *slot, u32 u) {
-	const u32 *wp = reinterpret_cast<const u32 *> (slot) + (u >> 5);
-	const u32 w0 = wp[0], w1 = wp[1], w2 = wp[2];
+// The three window words from the one that holds slot-relative bit u of the lane whose slot starts at
+// window word `slot` (= 16 x lane): dword-aligned reads and a funnel shift (a byte-unaligned 8-byte LDS
+// read costs 5x the LDS time); word i of the window lives at win[i + i / 16].
+OTZ_DEV void otz_k1_words(const otz_k1_lds &L, u32 slot, u32 u, u32 &w0, u32 &w1, u32 &w2) {
+	const u32 i0 = slot + otz_opaque (u >> 5), i1 = i0 + 1u, i2 = i0 + 2u;
+	w0 = L.win[i0 + (i0 >> 4)];
+	w1 = L.win[i1 + (i1 >> 4)];
+	w2 = L.win[i2 + (i2 >> 4)];
+}
+OTZ_DEV otz_k1_tok otz_k1_decode(const otz_k1_lds &L, u32 slot, u32 u) {
+	u32 w0, w1, w2;
+	otz_k1_words (L, slot, u, w0, w1, w2);
 	return otz_k1_decode_bits (L, otz_alignbit (w1, w0, u), otz_alignbit (w2, w1, u));
 }
 
 // The step of the walks' loops.  Both kernels of the DEFLATE decode are bound by VALU issue (a
 // wave64 VALU instruction holds its SIMD for four cycles; scalar instructions issue beside it), so
-// this is written to the instruction: ~22 VALU instructions per token --
-//   3 slot words (2: address) + 2 funnel shifts, literal/length lookup (2: address), 3 field
+// this is written to the instruction: ~27 VALU instructions per token --
+//   3 window words (7: addresses) + 2 funnel shifts, literal/length lookup (2: address), 3 field
 //   extractions, the special test, funnel shift + distance lookup (3), B, "a distance follows"
 //   + select (2), the token's bits and bytes (3 three-operand adds / bit-field extracts).
 // Lanes leave the loops through the execution mask (scalar instructions), nothing is selected
@@ -494,9 +514,9 @@ struct otz_k1_step {
 	u32 ob;   // bytes it yields
 	bool stop;
 };
-OTZ_DEV otz_k1_step otz_k1_hot(const otz_k1_lds &L, const u8 *slot, u32 u) {
-	const u32 *wp = reinterpret_cast<const u32 *> (slot) + otz_opaque (u >> 5); // (opaque: shift, then one shift-and-add)
-	const u32 w0 = wp[0], w1 = wp[1], w2 = wp[2];
+OTZ_DEV otz_k1_step otz_k1_hot(const otz_k1_lds &L, u32 slot, u32 u) {
+	u32 w0, w1, w2;
+	otz_k1_words (L, slot, u, w0, w1, w2);
 	const u32 lo = otz_alignbit (w1, w0, u), hi = otz_alignbit (w2, w1, u);
 	u32 e = L.lit[lo & ((1u << OTZ_K1_LROOT) - 1u)];
 	u32 xb = otz_bfe (e, 4, 3);
@@ -523,7 +543,7 @@ OTZ_DEV otz_k1_step otz_k1_hot(const otz_k1_lds &L, const u8 *slot, u32 u) {
 }
 
 // How a walk that stopped at slot-relative bit u ends: the exit word.
-OTZ_DEV u32 otz_k1_classify(const otz_k1_lds &L, const u8 *slot, u32 u, u32 e, u32 limit, bool capped) {
+OTZ_DEV u32 otz_k1_classify(const otz_k1_lds &L, u32 slot, u32 u, u32 e, u32 limit, bool capped) {
 	if (capped) {
 		return OTZ_X_MAKE (OTZ_X_CAP, u); // token budget used up
 	}
@@ -567,7 +587,7 @@ struct otz_k1_ws {
 // iterations [n0, n1) for the lanes that are still walking (the caller's execution mask); returns
 // false for a lane that has stopped
 template <bool SPEC, bool EARLY>
-OTZ_DEV bool otz_k1_walk_span(const otz_k1_lds &L, const u8 *slot, otz_k1_ws &W, u32 n0, u32 n1, u32 s, u32 e, u32 lim2, const otz_ix_item *rowsA, u64 bmA, u32 nckA) {
+OTZ_DEV bool otz_k1_walk_span(const otz_k1_lds &L, u32 slot, otz_k1_ws &W, u32 n0, u32 n1, u32 s, u32 e, u32 lim2, const otz_ix_item *rowsA, u64 bmA, u32 nckA) {
 	const u32 lane = otz_lane ();
 	for (u32 n = n0; n < n1; n++) {
 		if (!SPEC) {
@@ -617,7 +637,7 @@ OTZ_DEV bool otz_k1_walk_span(const otz_k1_lds &L, const u8 *slot, otz_k1_ws &W,
 }
 
 template <bool SPEC>
-OTZ_DEV otz_k1_path otz_k1_walk(const otz_k1_lds &L, const u8 *slot, bool run, u32 start, u32 s, u32 e, u32 limit,
+OTZ_DEV otz_k1_path otz_k1_walk(const otz_k1_lds &L, u32 slot, bool run, u32 start, u32 s, u32 e, u32 limit,
 	otz_ix_item *rows, const otz_ix_item *rowsA, u64 bmA, u32 nckA) {
 	const u32 lane = otz_lane ();
 	// a token that starts in front of e ends in front of e + 48: the clamp changes nothing for
@@ -852,22 +872,18 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 		while (!block_done && status == 0) {
 			const u32 rb = (u32) (abs_bit >> 3), phi = (u32) (abs_bit & 7u);
 			const int64_t slot0 = (int64_t)rb + 64 * (int64_t)lane - (int64_t) (OTZ_K1_WARM / 8u); // entry byte of the slot's byte 0
-			u8 *const slot = &L.slots[lane * OTZ_K1_SLOT];
-			otz_wave_sync (); // prologue scratch / previous round's slots are dead
-			for (u32 k = 0; k < OTZ_K1_SLOT / 16u; k++) {
-				const otz_u4 v = otz_k1_ld16 (in, n_in, slot0 + 16 * (int64_t)k);
-				u32 *d = reinterpret_cast<u32 *> (slot + 16u * k);
-				d[0] = v.x;
-				d[1] = v.y;
-				d[2] = v.z;
-				d[3] = v.w;
-			}
+			const u32 slot = 16u * lane; // window word of this lane's slot byte 0
+			otz_wave_sync (); // prologue scratch / previous round's window are dead
 			{
-				const otz_u4 v = otz_k1_ld16 (in, n_in, slot0 + 16 * (int64_t) (OTZ_K1_SLOT / 16u));
-				u32 *d = reinterpret_cast<u32 *> (slot + 16u * (OTZ_K1_SLOT / 16u));
-				d[0] = v.x;
-				d[1] = v.y;
-				d[2] = v.z;
+				const int64_t win0 = (int64_t)rb - (int64_t) (OTZ_K1_WARM / 8u); // entry byte of window byte 0
+				for (u32 c = lane; c < OTZ_K1_WIN_BYTES / 16u; c += 64u) { // coalesced 16-byte loads, 4 words each
+					const otz_u4 v = otz_k1_ld16 (in, n_in, win0 + 16 * (int64_t)c);
+					u32 *d = &L.win[4u * c + (c >> 2)]; // (4c .. 4c+3 lie inside one group of 16: one padding offset)
+					d[0] = v.x;
+					d[1] = v.y;
+					d[2] = v.z;
+					d[3] = v.w;
+				}
 			}
 			otz_wave_sync ();
 			// slot-relative bit coordinates: the lane's segment is [s, e)

@@ -41,7 +41,7 @@ static_assert (OTZ_NT * OTZ_S_BITS / 8 + 512 <= OTZ_STAGE_BYTES, "stage must cov
 static_assert (sizeof (otz_ix_head) == 32 && sizeof (otz_ix_block) == 32 && sizeof (otz_ix_item) == 8, "index layout");
 
 #ifndef OTZ_K1_WPE
-#define OTZ_K1_WPE 4
+#define OTZ_K1_WPE 5 // 7.6 KB of LDS admit 21 index wavefronts per CU: registers (<= 96) must not cut that to 16
 #endif
 #ifndef OTZ_ZS_WPE
 #define OTZ_ZS_WPE 4 // the Zstandard kernel's LDS (10.6 KB) admits 15 wavefronts per CU: registers must not halve that

@@ -17,7 +17,7 @@ def _run(items):
 def test_lds_budget_allows_two_workgroups_per_cu():
     assert emu_lib().emu_lds_bytes_inflate() <= 80 * 1024
     assert emu_lib().emu_lds_bytes_copy() <= 16 * 1024
-    assert emu_lib().emu_lds_bytes_index() <= 10 * 1024  # sixteen index wavefronts per CU
+    assert emu_lib().emu_lds_bytes_index() <= 8 * 1024  # twenty index wavefronts per CU
 
 
 def test_workgroup_per_entry_routine_alone():

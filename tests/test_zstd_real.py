@@ -20,7 +20,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import pyoracle as O  # noqa: E402
-from oracle import zstdlib as Z  # noqa: E402
+from tools import zstdlib as Z  # noqa: E402
 from helpers import ST_OK, emu_decode  # noqa: E402
 
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "zstd_frames.json")))

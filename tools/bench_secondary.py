@@ -16,7 +16,9 @@ import numpy as np
 import torch
 
 import otezip_amd as oz
+from otezip_amd import corpus
 from otezip_amd import corpus, _native as N
+from tools import zstd_corpus
 
 
 def timed(fn, steps=5, warm=1):
@@ -64,8 +66,8 @@ def main():
     bufs = corpus.text_buffers(min(n, 10000), 65536, first=50000)
     arc_rz = ents_rz = None
     try:  # real Zstandard frames (libzstd of the image makes them): configs[2] shape, and 64 KiB entries like configs[1]
-        arc_rz, ents_rz = corpus.build_zstd_real(max(n // 4, 100), 262144)
-        arc_rz64, ents_rz64 = corpus.build_zstd_real(n, 65536)
+        arc_rz, ents_rz = zstd_corpus.build_zstd_real(max(n // 4, 100), 262144)
+        arc_rz64, ents_rz64 = zstd_corpus.build_zstd_real(n, 65536)
     except Exception as ex:  # no libzstd: nothing to measure
         print("real zstd corpus unavailable: %r" % (ex,), file=sys.stderr)
     oz.init(0)

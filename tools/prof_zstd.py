@@ -9,7 +9,9 @@ import numpy as np
 import torch
 
 import otezip_amd as oz
+from otezip_amd import corpus
 from otezip_amd import corpus, _native as N
+from tools import zstd_corpus
 
 NAMES = ["literals", "seq tables", "seq decode", "seq execute", "staging", "xxh64"]
 
@@ -17,7 +19,7 @@ NAMES = ["literals", "seq tables", "seq decode", "seq execute", "staging", "xxh6
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
     size = int(sys.argv[2]) if len(sys.argv) > 2 else 262144
-    arc, ents = corpus.build_zstd_real(n, size)
+    arc, ents = zstd_corpus.build_zstd_real(n, size)
     oz.init(0)
     L = oz.lib()
     tab = [(e["method"], e["data_off"], e["comp_size"], e["uncomp_size"], e["crc32"]) for e in ents]

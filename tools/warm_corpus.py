@@ -7,6 +7,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from otezip_amd import corpus
+from tools import zstd_corpus
 
 
 def main():
@@ -20,8 +21,8 @@ def main():
         corpus.build_archive(k, 65536)
     corpus.text_buffers(10000, 65536, first=50000)
     try:
-        corpus.build_zstd_real(max(n // 4, 100), 262144)
-        corpus.build_zstd_real(n, 65536)
+        zstd_corpus.build_zstd_real(max(n // 4, 100), 262144)
+        zstd_corpus.build_zstd_real(n, 65536)
     except Exception as ex:
         print("real zstd corpus unavailable: %r" % (ex,))
     print("corpora cached")
