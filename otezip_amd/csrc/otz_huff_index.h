@@ -593,7 +593,7 @@ OTZ_DEV bool otz_k1_walk_span(const otz_k1_lds &L, u32 slot, otz_k1_ws &W, u32 n
 		if (!SPEC) {
 			while (W.cpos < W.u) { // (rare: passed a checkpoint of walk A without landing on it)
 				W.c++;
-				W.cpos = W.c < nckA ? rowsA[W.c * 64u + lane].bit : OTZ_K1_NONE;
+				W.cpos = W.c < nckA ? rowsA[W.c * 64u + otz_opaque (lane)].bit : OTZ_K1_NONE;
 			}
 			bool hit = W.cpos == W.u;
 			if (EARLY) { // the early token starts of walk A
@@ -666,9 +666,9 @@ OTZ_DEV otz_k1_path otz_k1_walk(const otz_k1_lds &L, u32 slot, bool run, u32 sta
 	W.merged = W.capped = false;
 	W.c = 1; // walk B: walk A's next checkpoint at or behind u (row 0 is its first token: bmA has it)
 	W.cpos = OTZ_K1_NONE;
-	W.row = rows + lane;
+	W.row = rows + otz_opaque (lane); // (opaque: a per-lane 64-bit pointer kept alive across the whole entry is a spilled register pair)
 	if (!SPEC) {
-		W.cpos = run && nckA > 1u ? rowsA[64u + lane].bit : OTZ_K1_NONE;
+		W.cpos = run && nckA > 1u ? rowsA[64u + otz_opaque (lane)].bit : OTZ_K1_NONE;
 	}
 	if (alive) {
 		W.capped = true;
@@ -933,7 +933,7 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 						onA = W.mpos != OTZ_K1_NONE;
 						mp = W.mpos;
 						jm = early ? j : W.mrow * OTZ_IX_G;
-						offA = early ? ob : onA ? rowsA[W.mrow * 64u + lane].out : 0u;
+						offA = early ? ob : onA ? rowsA[W.mrow * 64u + otz_opaque (lane)].out : 0u;
 						exit_cur = onA ? A.exit : W.exit;
 					}
 				}
@@ -998,7 +998,7 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 #pragma unroll 2
 					for (u32 r = 0; r < OTZ_K1_ROWS; r++) {
 						if (acc && r < nB_items) {
-							otz_ix_item it = rowsB[r * 64u + lane];
+							otz_ix_item it = rowsB[r * 64u + otz_opaque (lane)];
 							it.bit += bit0;
 							it.out += obase;
 							dst[r] = it;
@@ -1014,7 +1014,7 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 #pragma unroll 4
 				for (u32 r = 1; r < OTZ_K1_ROWS; r++) {
 					if (acc && tailA && r >= rA0 && r < nckA) {
-						otz_ix_item it = rowsA[r * 64u + lane];
+						otz_ix_item it = rowsA[r * 64u + otz_opaque (lane)];
 						it.bit += bit0;
 						it.out += obase + bytesB - offA;
 						dst[nB_items + 1u + r - rA0] = it;

@@ -79,10 +79,10 @@ def test_apply_kernel_keeps_two_workgroups_per_cu(native):
 
 def test_index_kernel_keeps_five_waves_per_simd(native):
     """One wavefront per entry, 20 of them per CU: <= 8 KB of LDS (checked in test_emu_parity) and <= 96
-    VGPRs.  The register cap costs a handful of spilled registers in the entry's prologue and epilogue
-    (<= 32 bytes per lane; none inside the walks: tools/isa_loops.py shows the loops' instruction mix)."""
+    VGPRs, and no scratch segment: spills cost memory round trips, and on this pool a kernel with a
+    scratch segment has hung rocprofv3's --pmc passes."""
     vgprs, scratch, occ = _kernel_resources("otz_index_kernel")
-    assert vgprs <= 96 and scratch <= 32 and occ >= 5, (vgprs, scratch, occ)
+    assert vgprs <= 96 and scratch == 0 and occ >= 5, (vgprs, scratch, occ)
 
 
 def test_fails_loudly_without_a_gpu(native):

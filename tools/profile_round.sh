@@ -30,6 +30,8 @@ echo "[profile] SQ counters"
 tools/sq_counters.sh ${tag} > $out/sq.log 2>&1; cp gpurun_out/sq_summary_${tag}.json $out/sq_summary.json 2>/dev/null; grep -c SQ_ $out/sq_summary.json
 echo "[profile] phases"
 timeout -k 10 200 python3 tools/prof_phases.py 4000 > $out/phases.txt 2>&1; grep -v "amdgpu.ids\|  0 cyc" $out/phases.txt
+echo "[profile] Zstandard kernel phases"
+timeout -k 10 200 python3 tools/prof_zstd.py 2500 262144 > $out/zstd_phases.txt 2>&1; grep -v "amdgpu.ids" $out/zstd_phases.txt
 echo "[profile] encoder: throughput, ratio, phases"
 timeout -k 10 200 python3 tools/prof_encode.py 10000 > $out/encode_phases.txt 2>&1; grep -v "amdgpu.ids" $out/encode_phases.txt
 echo "[profile] LDS access costs"
