@@ -46,7 +46,11 @@
 #define WIN_MAX_ENTRIES 1024u /* (pinning host memory costs ~0.25 ms per MB: windows stay small enough to recycle three sets) */
 #define WIN_MAX_COMP (48ull << 20)
 #define WIN_MAX_OUT (96ull << 20)
-#define READ_THREADS 4 /* a window's stretch of the file is read by this many pread()s in parallel */
+#define READ_THREADS_MAX 16
+static int g_read_threads = 4; /* a window's stretch of the file is read by this many pread()s in parallel (OTEZIP_READ_THREADS) */
+static int g_ahead_min = 1;    /* windows kept in preparation behind the current one, at least (OTEZIP_READ_AHEAD); measured on the
+                                * bench archive (tools/api_rates.sh): 8-16 threads or a depth of 2-4 are no faster than 4 / 1 --
+                                * the D2H copy of the outputs is what a warm pass waits for */
 #define AHEAD_MAX 8    /* windows prepared ahead of a sequential reader: one per device (OTEZIP_GPU_DEVICES), at most this many */
 #define FLIGHTS_MAX (AHEAD_MAX + 1) /* encode batches in flight while a flush writes: one per device + the one being written */
 /* Pending adds are flushed at this many source bytes / entries: the ZIP32 limits, so that in
@@ -185,6 +189,15 @@ static int gpu_up(void) {
 			}
 		}
 		(void)ozg_use_device (g_dev0);
+		{
+			const char *rt = getenv ("OTEZIP_READ_THREADS"), *ra = getenv ("OTEZIP_READ_AHEAD");
+			if (rt && atoi (rt) >= 1) {
+				g_read_threads = atoi (rt) > READ_THREADS_MAX ? READ_THREADS_MAX : atoi (rt);
+			}
+			if (ra && atoi (ra) >= 1) {
+				g_ahead_min = atoi (ra) > AHEAD_MAX ? AHEAD_MAX : atoi (ra);
+			}
+		}
 		g_ndev = want;
 		g_gpu_state = 1;
 		TRACE ("devices ready: %d from %d", g_ndev, g_dev0);
@@ -610,10 +623,10 @@ static void *pread_run(void *p) {
 }
 static int read_span(FILE *fp, uint8_t *dst, uint64_t off, uint64_t len) {
 	const int fd = fileno (fp);
-	int nt = len >= ((uint64_t)4 << 20) ? READ_THREADS : 1;
-	struct pread_job job[READ_THREADS];
-	pthread_t th[READ_THREADS];
-	int started[READ_THREADS];
+	int nt = len >= ((uint64_t)4 << 20) ? g_read_threads : 1;
+	struct pread_job job[READ_THREADS_MAX];
+	pthread_t th[READ_THREADS_MAX];
+	int started[READ_THREADS_MAX];
 	const uint64_t piece = ((len + (uint64_t)nt - 1u) / (uint64_t)nt + 4095u) & ~(uint64_t)4095u;
 	for (int i = 0; i < nt; i++) {
 		const uint64_t o = piece * (uint64_t)i;
@@ -1191,7 +1204,8 @@ zip_file_t *zip_fopen_index(zip_t *za, zip_uint64_t index, zip_flags_t flags) {
 		/* a caller that walks the archive gets the next windows prepared while it uses this one: one per
 		 * device, so that every GPU of OTEZIP_GPU_DEVICES has a window in flight */
 		if (z->seq_hits >= 2) {
-			const int depth = g_ndev > 1 ? (g_ndev < AHEAD_MAX ? g_ndev : AHEAD_MAX) : 1;
+			int depth = g_ndev > g_ahead_min ? g_ndev : g_ahead_min; /* (one per device at least) */
+			depth = depth < AHEAD_MAX ? depth : AHEAD_MAX;
 			while (z->n_ahead < depth) {
 				const struct window *last = z->n_ahead ? z->ahead[z->n_ahead - 1] : z->win;
 				const zip_uint64_t nf = last->first + last->count;
