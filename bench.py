@@ -40,13 +40,19 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def load_shard(rank, n, size, method, cache_dir):
-    """The rank's archive image + entry table, cached on local disk between runs."""
+def load_shard(rank, n, size, method, cache_dir, wait_for_other=False):
+    """The rank's archive image + entry table, cached on local disk between runs.
+    wait_for_other: another process of this job generates this shard: wait for its files instead of
+    generating the same bytes again (N ranks x 16 generator processes at once is what this avoids)."""
     import numpy as np
     from otezip_amd import corpus
     os.makedirs(cache_dir, exist_ok=True)
     tag = "m%d_n%d_s%d_r%d_v2" % (method, n, size, rank)
     p_arc, p_ent = os.path.join(cache_dir, tag + ".zip"), os.path.join(cache_dir, tag + ".npy")
+    if wait_for_other:
+        t0 = time.time()
+        while not (os.path.exists(p_arc) and os.path.exists(p_ent)) and time.time() - t0 < 900:
+            time.sleep(0.5)
     if os.path.exists(p_arc) and os.path.exists(p_ent):
         with open(p_arc, "rb") as f:
             arc = f.read()
@@ -179,7 +185,10 @@ def main():
 
     # synthetic archive first: the generator forks workers, which must happen before HIP is up
     strong = args.scaling == "strong" and world > 1
-    arc, ent = load_shard(0 if strong else rank, args.entries, args.entry_size, args.method, args.cache_dir)
+    # every rank decodes a 10 000-entry shard of its own (weak scaling); the shards are the same synthetic
+    # archive -- rank 0 generates it once, the others wait for its cache files -- so that N ranks do not
+    # start N x 16 generator processes at the same moment
+    arc, ent = load_shard(0, args.entries, args.entry_size, args.method, args.cache_dir, wait_for_other=local_rank != 0)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: otezip-amd has no CPU path")
     dev_index = 0 if args.share_device else local_rank
@@ -264,7 +273,7 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "configs[1]: %d x %d B enwik-style entries %s, zlib-6 raw DEFLATE, ratio %.2f, "
                                    "archive image resident in HBM" % (args.entries, args.entry_size,
-                                                                       "in ONE archive split over the GPUs" if strong else "per GPU",
+                                                                       "in ONE archive split over the GPUs" if strong else "per GPU (the same synthetic archive on every GPU)",
                                                                        out_bytes / max(comp_bytes, 1)),
                        "entries_per_gpu": n, "entry_bytes": args.entry_size, "method": args.method,
                        "parallelism": ("one descriptor table broadcast over RCCL, entries split %d-way by bytes" if strong else

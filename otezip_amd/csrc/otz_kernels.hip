@@ -43,6 +43,9 @@ static_assert (sizeof (otz_ix_head) == 32 && sizeof (otz_ix_block) == 32 && size
 #ifndef OTZ_K1_WPE
 #define OTZ_K1_WPE 5 // 7.6 KB of LDS admit 21 index wavefronts per CU: registers (<= 96) must not cut that to 16
 #endif
+#ifndef OTZ_K2_WPE
+#define OTZ_K2_WPE 4
+#endif
 #ifndef OTZ_ZS_WPE
 #define OTZ_ZS_WPE 4 // the Zstandard kernel's LDS (10.6 KB) admits 15 wavefronts per CU: registers must not halve that
 #endif
@@ -131,7 +134,7 @@ otz_inflate_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result 
 // Two workgroups per CU (16 waves, 4 per SIMD) need <= 128 VGPRs: pin that occupancy so a
 // register-hungry change fails the resource check in tests/test_abi.py instead of
 // silently halving the number of entries in flight.
-extern "C" __global__ void __launch_bounds__ (OTZ_NT) __attribute__ ((amdgpu_waves_per_eu (4, 4)))
+extern "C" __global__ void __launch_bounds__ (OTZ_NT) __attribute__ ((amdgpu_waves_per_eu (OTZ_K2_WPE, OTZ_K2_WPE)))
 otz_apply_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *results, u32 first, u32 n, u64 src_len, u64 dst_len, ozg_limits lim,
 	const u8 *arena, const otz_region *regions, const otz_ix_head *heads, u64 *prof, u64 *end_bits) {
 	extern __shared__ __attribute__ ((aligned (16))) u8 otz_smem[];
