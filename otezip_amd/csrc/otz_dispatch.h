@@ -64,7 +64,7 @@ OTZ_DEV bool otz_run_index(otz_k1_lds &L, const u8 *src, u8 *dst, const ozg_entr
 }
 
 // DEFLATE entries, second half: index -> bytes
-OTZ_DEV void otz_run_apply(otz_inflate_lds &L, const u8 *src, u8 *dst, const ozg_entry &e, ozg_result *r, const ozg_limits &lim, const otz_ix_head *head, const u8 *region, u64 *prof, u64 *end_bit = nullptr) {
+OTZ_DEV void otz_run_apply(otz_apply_lds &L, const u8 *src, u8 *dst, const ozg_entry &e, ozg_result *r, const ozg_limits &lim, const otz_ix_head *head, const u8 *region, u64 *prof, u64 *end_bit = nullptr) {
 	if (e.method != OZG_METHOD_DEFLATE) {
 		return;
 	}
@@ -78,7 +78,19 @@ OTZ_DEV void otz_run_apply(otz_inflate_lds &L, const u8 *src, u8 *dst, const ozg
 	J.out = dst + e.dst_off;
 	J.out_cap = e.uncomp_size;
 	J.prof = prof;
-	otz_apply_entry (L, J, e.crc32, head, region, r, end_bit);
+	otz_apply_entry (L, J, head, region, r, end_bit);
+}
+
+// CRC-32 of an entry's output for the kernels that leave it to a streaming pass (ref
+// src/lib/otezip.c:667-679: m bytes: for DEFLATE the whole uncomp_size, a zero-filled tail included).
+// keep_flags: the decoder's flags stay (DEFLATE), else they are replaced.  L.t4/L.a4 are loaded.
+OTZ_DEV void otz_run_crc(otz_copy_lds &L, const u8 *dst, const ozg_entry &e, ozg_result *r, u32 m, bool keep_flags) {
+	const u32 R = otz_stream_crc (L, dst + e.dst_off, nullptr, m, false);
+	if (otz_tid () == 0) {
+		const u32 crc = ~(otz_gf_mul (0xFFFFFFFFu, otz_xpow_bytes (m)) ^ R);
+		r->crc32 = crc;
+		r->flags = (keep_flags ? r->flags : 0u) | (crc != e.crc32 ? OZG_F_CRC_MISMATCH : 0u);
+	}
 }
 
 // every other method, including the unsupported ones (status OZG_ST_METHOD)

@@ -80,7 +80,9 @@ static_assert ((OTZ_IX_G & (OTZ_IX_G - 1u)) == 0, "power of two");
 //           bit 15: link ([3:0] index width, [14:4] sub-table start - root size)
 #define OTZ_K1_SPECIAL 0x70u
 #define OTZ_K1_DBAD 0x3FFFu
+#ifndef OTZ_K1_LROOT
 #define OTZ_K1_LROOT 10u
+#endif
 #define OTZ_K1_DROOT 8u
 // Sub-table room: zlib's worst cases (ENOUGH: 1332 / 592 entries) need adversarial code sets; streams that
 // compressors write stay far below these sizes, and a block that does not fit sends its entry to the

@@ -166,8 +166,10 @@ struct otz_job {
 		} \
 	} while (0)
 
-OTZ_DEV void otz_set_status(otz_inflate_lds &L, int st) { otz_lds_store (&L.status, (u32)st); }
-OTZ_DEV int otz_get_status(const otz_inflate_lds &L) { return (int)otz_lds_load (&L.status); }
+template <class LDS>
+OTZ_DEV void otz_set_status(LDS &L, int st) { otz_lds_store (&L.status, (u32)st); }
+template <class LDS>
+OTZ_DEV int otz_get_status(const LDS &L) { return (int)otz_lds_load (&L.status); }
 
 OTZ_DEV u32 otz_mk_lit_entry(u32 sym, u32 len) {
 	if (sym < 256u) {
@@ -320,7 +322,8 @@ OTZ_DEV u32 otz_block_scan_incl(u32 v, u32 *scratch, u32 *total) {
 
 // Stage OTZ_STAGE_BYTES of input starting at the 16-byte-aligned global address at
 // or below in+byte0; zero beyond the entry. Returns the skew (in+byte0 - aligned).
-OTZ_DEV u32 otz_stage_load(otz_inflate_lds &L, const otz_job &J, u32 byte0) {
+template <class LDS>
+OTZ_DEV u32 otz_stage_load(LDS &L, const otz_job &J, u32 byte0) {
 	const u8 *p = J.in + byte0;
 	u32 skew = (u32) ((uintptr_t)p & 15u);
 	const u8 *ga = p - skew;
@@ -455,7 +458,8 @@ OTZ_DEV bool otz_canon_build(otz_canon &c, const u32 *hist) {
 // among the symbols of the same length, and the rank comes from wavefront ballots --
 // no sorted symbol list is ever materialised.  The symbol then writes its own root
 // slots (code no longer than the root), or claims a sub-table under its root slot.
-OTZ_DEV bool otz_build_tables(otz_inflate_lds &L, u32 hlit, u32 hdist) {
+template <class LDS>
+OTZ_DEV bool otz_build_tables(LDS &L, u32 hlit, u32 hdist) {
 	static_assert (OTZ_NT >= 384 && OTZ_NT >= (1u << OTZ_LIT_ROOT), "one work-item per symbol and per literal root slot");
 	constexpr u32 LRSZ = 1u << OTZ_LIT_ROOT, DRSZ = 1u << OTZ_DIST_ROOT;
 	const u32 tid = otz_opaque (otz_tid ()), lane = otz_lane (), wave = otz_wave ();
@@ -678,7 +682,8 @@ OTZ_DEV void otz_wave_min_tid(u32 *p, bool pred) {
 
 // Every work-item calls this with the same st: the barriers keep the write to
 // L.status away from work-items that are still reading it.
-OTZ_DEV void otz_fail_all(otz_inflate_lds &L, int st) {
+template <class LDS>
+OTZ_DEV void otz_fail_all(LDS &L, int st) {
 	otz_sync ();
 	if (otz_tid () == 0) {
 		otz_set_status (L, st);

@@ -43,9 +43,13 @@ static_assert (sizeof (otz_ix_head) == 32 && sizeof (otz_ix_block) == 32 && size
 #ifndef OTZ_K1_WPE
 #define OTZ_K1_WPE 5 // 7.6 KB of LDS admit 21 index wavefronts per CU: registers (<= 96) must not cut that to 16
 #endif
-#ifndef OTZ_K2_WPE
-#define OTZ_K2_WPE 4
+#ifndef OTZ_K2_WGS
+#define OTZ_K2_WGS 4 // apply workgroups per CU
 #endif
+#ifndef OTZ_K2_WPE
+#define OTZ_K2_WPE (2 * OTZ_K2_WGS)
+#endif
+static_assert (sizeof (otz_apply_lds) <= 160 * 1024 / OTZ_K2_WGS, "apply workgroups per CU");
 #ifndef OTZ_ZS_WPE
 #define OTZ_ZS_WPE 4 // the Zstandard kernel's LDS (10.6 KB) admits 15 wavefronts per CU: registers must not halve that
 #endif
@@ -131,9 +135,9 @@ otz_inflate_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result 
 	}
 }
 
-// Two workgroups per CU (16 waves, 4 per SIMD) need <= 128 VGPRs: pin that occupancy so a
-// register-hungry change fails the resource check in tests/test_abi.py instead of
-// silently halving the number of entries in flight.
+// OTZ_K2_WGS workgroups per CU (8 waves each, 2 per SIMD): pin the occupancy the LDS footprint
+// allows so a register-hungry change fails the resource check in tests/test_abi.py instead of
+// silently cutting the number of entries in flight.
 extern "C" __global__ void __launch_bounds__ (OTZ_NT) __attribute__ ((amdgpu_waves_per_eu (OTZ_K2_WPE, OTZ_K2_WPE)))
 otz_apply_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *results, u32 first, u32 n, u64 src_len, u64 dst_len, ozg_limits lim,
 	const u8 *arena, const otz_region *regions, const otz_ix_head *heads, u64 *prof, u64 *end_bits) {
@@ -142,7 +146,7 @@ otz_apply_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *r
 	if (i >= n) {
 		return;
 	}
-	otz_inflate_lds &L = *reinterpret_cast<otz_inflate_lds *> (otz_smem);
+	otz_apply_lds &L = *reinterpret_cast<otz_apply_lds *> (otz_smem);
 	const ozg_entry e = entries[i];
 	if (e.method != OZG_METHOD_DEFLATE) {
 		return;
@@ -232,13 +236,22 @@ otz_zstd_crc_kernel(u8 *dst, const ozg_entry *entries, ozg_result *results, u32 
 	otz_crc_load_slice4 (L.t4);
 	otz_crc_load_adv4k (L.a4);
 	otz_sync ();
-	const u32 m = results[i].total_out;
-	const u32 R = otz_stream_crc (L, dst + entries[i].dst_off, nullptr, m, false);
-	if (otz_tid () == 0) {
-		const u32 crc = ~(otz_gf_mul (0xFFFFFFFFu, otz_xpow_bytes (m)) ^ R);
-		results[i].crc32 = crc;
-		results[i].flags = crc != entries[i].crc32 ? OZG_F_CRC_MISMATCH : 0u;
+	otz_run_crc (L, dst, entries[i], &results[i], results[i].total_out, false);
+}
+
+// CRC-32 of the DEFLATE entries otz_apply_kernel decoded
+extern "C" __global__ void __launch_bounds__ (256)
+otz_out_crc_kernel(const u8 *dst, const ozg_entry *entries, ozg_result *results, u32 first, u32 n) {
+	extern __shared__ __attribute__ ((aligned (16))) u8 otz_smem[];
+	const u32 i = first + blockIdx.x;
+	if (i >= n || entries[i].method != OZG_METHOD_DEFLATE || results[i].status != OZG_ST_OK) {
+		return;
 	}
+	otz_copy_lds &L = *reinterpret_cast<otz_copy_lds *> (otz_smem);
+	otz_crc_load_slice4 (L.t4);
+	otz_crc_load_adv4k (L.a4);
+	otz_sync ();
+	otz_run_crc (L, dst, entries[i], &results[i], entries[i].uncomp_size, true);
 }
 
 extern "C" __global__ void __launch_bounds__ (256)
@@ -735,8 +748,10 @@ int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, 
 			hipLaunchKernelGGL (g_prof ? otz_index_prof_kernel : otz_index_kernel, dim3 (n), dim3 (64), sizeof (otz_k1_lds), s, (const u8 *)d_src, (u8 *)d_dst, d_entries, 0u, n,
 				(u64)src_len, (u64)dst_len, g_limits, ws.arena, ws.regions, ws.heads, ws.ovf, g_prof);
 			OZG_HIP (hipGetLastError ());
-			hipLaunchKernelGGL (otz_apply_kernel, dim3 (n), dim3 (OTZ_NT), sizeof (otz_inflate_lds), s, (const u8 *)d_src, (u8 *)d_dst,
+			hipLaunchKernelGGL (otz_apply_kernel, dim3 (n), dim3 (OTZ_NT), sizeof (otz_apply_lds), s, (const u8 *)d_src, (u8 *)d_dst,
 				d_entries, d_results, 0u, n, (u64)src_len, (u64)dst_len, g_limits, (const u8 *)ws.arena, ws.regions, ws.heads, g_prof, d_end_bits);
+			OZG_HIP (hipGetLastError ());
+			hipLaunchKernelGGL (otz_out_crc_kernel, dim3 (n), dim3 (256), sizeof (otz_copy_lds), s, (const u8 *)d_dst, d_entries, d_results, 0u, n);
 			OZG_HIP (hipGetLastError ());
 		} else {
 			OZG_HIP (hipEventRecord (ws.fork, s));
@@ -753,8 +768,10 @@ int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, 
 				hipLaunchKernelGGL (otz_index_kernel, dim3 (e1 - e0), dim3 (64), sizeof (otz_k1_lds), cs, (const u8 *)d_src, (u8 *)d_dst, d_entries, e0, n,
 					(u64)src_len, (u64)dst_len, g_limits, ws.arena, ws.regions, ws.heads, ws.ovf, g_prof);
 				OZG_HIP (hipGetLastError ());
-				hipLaunchKernelGGL (otz_apply_kernel, dim3 (e1 - e0), dim3 (OTZ_NT), sizeof (otz_inflate_lds), cs, (const u8 *)d_src, (u8 *)d_dst,
+				hipLaunchKernelGGL (otz_apply_kernel, dim3 (e1 - e0), dim3 (OTZ_NT), sizeof (otz_apply_lds), cs, (const u8 *)d_src, (u8 *)d_dst,
 					d_entries, d_results, e0, n, (u64)src_len, (u64)dst_len, g_limits, (const u8 *)ws.arena, ws.regions, ws.heads, g_prof, d_end_bits);
+				OZG_HIP (hipGetLastError ());
+				hipLaunchKernelGGL (otz_out_crc_kernel, dim3 (e1 - e0), dim3 (256), sizeof (otz_copy_lds), cs, (const u8 *)d_dst, d_entries, d_results, e0, n);
 				OZG_HIP (hipGetLastError ());
 			}
 			for (int k = 0; k < 2; k++) {
@@ -912,7 +929,9 @@ int ozg_init(int device) {
 	if (!g_dev[device].ready) {
 		// (function attributes are per device)
 		OZG_HIP (hipFuncSetAttribute ((const void *)otz_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-			(int)sizeof (otz_inflate_lds)));
+			(int)sizeof (otz_apply_lds)));
+		OZG_HIP (hipFuncSetAttribute ((const void *)otz_out_crc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+			(int)sizeof (otz_copy_lds)));
 		OZG_HIP (hipFuncSetAttribute ((const void *)otz_inflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
 			(int)sizeof (otz_inflate_lds)));
 		OZG_HIP (hipFuncSetAttribute ((const void *)otz_index_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,

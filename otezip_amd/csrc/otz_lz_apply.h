@@ -1,46 +1,89 @@
 // otz_lz_apply.h -- second half of the DEFLATE decode: one 512-lane workgroup turns the
 // index of otz_index.h into the entry's bytes.  (ref: the output side of inflate(),
-// src/lib/deflate-dec.inc.c:693-812 -- literal store, do_copy_from_window :521-545 -- and
-// the CRC-32 of otezip_extract_entry, src/lib/otezip.c:667-679.)
+// src/lib/deflate-dec.inc.c:693-812 -- literal store, do_copy_from_window :521-545.)
 //
 // Per Huffman block: rebuild the decode tables from the stored code lengths (all lanes),
 // then take the block's items 512 at a time (fewer when their output would not fit one
-// round of the ring, or their bits the stage buffer): lane j decodes item j -- at most
-// OTZ_IX_G tokens between two known token boundaries, at a known output position.
-// Literals go to their final bytes of the LDS ring, matches are parked at their
-// destination and resolved in LDS once their source bytes are final (otz_inflate.h); the
-// ring is flushed with coalesced 16-byte stores and CRC'd on the way out.
+// round, or their bits the stage buffer): lane j decodes item j -- at most OTZ_IX_G tokens
+// between two known token boundaries, at a known output position.  Literals go to their
+// final bytes of the round buffer in LDS, matches are parked at their destination and
+// resolved once their source bytes are final; the round is then written out with coalesced
+// 16-byte stores.
+//
+// The kernel is bound by the latency of dependent LDS round trips, not by issue slots: what
+// buys time is wavefronts per CU.  So LDS holds only the round being decoded and the last
+// OTZ_A_WIN bytes before it; the rest of the 32 KiB LZ77 window is the entry's own output in
+// global memory, written at the end of every round -- a match that reaches further back reads
+// it from there (L2 hits: the bytes were stored microseconds ago by this CU).  The CRC-32 is
+// left to a streaming pass over the output (otz_out_crc_kernel).
 #pragma once
 
 #include "otz_inflate.h"
 #include "otz_index.h"
 
+#ifndef OTZ_A_RMAX
+#define OTZ_A_RMAX 16384u // output bytes per round
+#endif
+#ifndef OTZ_A_WIN
+#define OTZ_A_WIN 4096u   // bytes before the round kept in LDS (a multiple of 16)
+#endif
+#define OTZ_A_RBUF (OTZ_A_WIN + 16u + OTZ_A_RMAX) // + the last, partial 16-byte chunk before the window
+#define OTZ_A_FIN_WORDS (OTZ_A_RBUF / 32u + 2u)
+
+// rbuf[i] is output byte p0 + i of the entry (p0 a multiple of 16, everything before it is in
+// global memory); fin bit i: that byte is final.
+struct otz_apply_lds {
+	u8 rbuf[OTZ_A_RBUF + 32u]; // (+ what the wide reads of otz_resolve_list may touch past the end)
+	u32 lit_lut[OTZ_LIT_LUT];
+	u32 dist_lut[OTZ_DIST_LUT];
+	union {
+		u32 stage_w[OTZ_STAGE_WORDS];
+		u8 stage[OTZ_STAGE_BYTES];
+	};
+	union {
+		u32 fin[OTZ_A_FIN_WORDS];
+		u8 ll[320]; // table build: code lengths
+	};
+	u32 wcnt[6][16]; // table build: symbols of each code length per wavefront
+	otz_canon lit_c, dist_c;
+	u32 scan[8];
+	u32 status; // 0 while decoding, else the final status code
+	u32 flag;
+	u32 first_rej;
+	u32 last_out;
+	u32 dbg[4];
+	u64 prof_last;
+	u64 prof[16];
+};
+static_assert (OTZ_A_WIN % 16u == 0 && OTZ_A_RMAX % 32u == 0, "chunked flush and bitmap words");
+static_assert (OTZ_A_RBUF <= 65535u, "buffer positions fit 16 bits");
+
+// where the entry stands: opos = bytes decoded, flushed = bytes in global memory (a multiple of
+// 16 until the end), p0 = output position of rbuf[0]
+struct otz_a_pos {
+	u32 opos, flushed, p0;
+};
 
 // ---------------------------------------------------------------- placement
 //
 // Lane j decodes item j: at most OTZ_IX_G tokens from stage bit s_bit up to e_bit, first
-// output byte at absolute position o_abs.  Literals go to their final ring bytes (and are
-// marked final); a match is parked in the first three bytes of its own destination (23 bits:
+// output byte at buffer position ri.  Literals go to their final bytes (and are marked
+// final); a match is parked in the first three bytes of its own destination (23 bits:
 // distance-1 : 15, length-3 : 8 -- a match is at least three bytes long) and its destination
-// is noted.  The kernel is bound by VALU issue, so the loop is written to the instruction: lanes
-// leave it, and take the literal or the match branch, through the execution mask (scalar
-// instructions) -- nothing is computed for a lane and then selected away -- and a step reloads
-// its three stage words instead of sliding a window (~55 VALU instructions per token; the
-// unrolled select-based form took 129).
+// is noted.  Lanes leave the loop, and take the literal or the match branch, through the
+// execution mask (scalar instructions) -- nothing is computed for a lane and then selected
+// away -- and a step reloads its three stage words instead of sliding a window.
 // Afterwards the destinations of all matches of the round are written, in stream order, to
-// `list` (round-relative, u16): a prefix sum over the lanes' match counts gives every lane its
-// slice.  Returns the number of matches of the round.  All OTZ_NT work-items.
+// `list` (buffer positions, u16): a prefix sum over the lanes' match counts gives every lane
+// its slice.  Returns the number of matches of the round.  All OTZ_NT work-items.
 static_assert (OTZ_IX_G == 8u, "eight 16-bit destinations are packed into four 32-bit registers");
 static_assert (OTZ_NT * OTZ_IX_G * 2u <= OTZ_STAGE_BYTES, "the match list of a round fits the stage buffer");
-static_assert (OTZ_RMAX <= 65536u, "round-relative positions fit 16 bits");
-OTZ_DEV u32 otz_place_items(otz_inflate_lds &L, bool active, u32 s_bit, u32 e_bit, u32 o_abs, u32 round_base, u16 *list) {
+OTZ_DEV u32 otz_place_items(otz_apply_lds &L, bool active, u32 s_bit, u32 e_bit, u32 ri, u32 p0, u16 *list) {
 	u32 nm = 0;
 	u32 k0 = 0, k1 = 0, k2 = 0, k3 = 0; // the matches' destinations, newest in the low half of k0
 	u32 err = 0;                        // 1: the index and the stream disagree, 2: distance beyond the output start
 	u32 pos = s_bit;
 	if (active) {
-		u32 rel = o_abs - round_base; // round-relative output position
-		u32 ri = OTZ_RIDX (o_abs);
 		for (u32 i = 0; i < OTZ_IX_G; i++) {
 			if (pos >= e_bit) {
 				break;
@@ -51,10 +94,9 @@ OTZ_DEV u32 otz_place_items(otz_inflate_lds &L, bool active, u32 s_bit, u32 e_bi
 			const u32 e = otz_lut2<OTZ_LIT_ROOT> (L.lit_lut, lo);
 			const u32 len = e & 15u, kind = (e >> 4) & 3u;
 			if (kind == OTZ_K_LIT) {
-				L.ring[ri] = (u8) (e >> 16);
-				otz_lds_or (&L.fin[rel >> 5], 1u << (rel & 31u));
-				rel += 1u;
-				ri = ri + 1u == OTZ_RING ? 0u : ri + 1u;
+				L.rbuf[ri] = (u8) (e >> 16);
+				otz_lds_or (&L.fin[ri >> 5], 1u << (ri & 31u));
+				ri += 1u;
 				pos += len;
 			} else if (kind == OTZ_K_LEN) {
 				const u32 xb = (e >> 8) & 15u;
@@ -68,27 +110,20 @@ OTZ_DEV u32 otz_place_items(otz_inflate_lds &L, bool active, u32 s_bit, u32 e_bi
 					break;
 				}
 				const u32 dist = (d >> 16) + otz_bfe (db, dl, dxb);
-				if (dist > round_base + rel) {
+				if (dist > p0 + ri) {
 					err = 2; // ref reads window bytes nobody wrote (:524): no parity, fail cleanly
 					break;
 				}
 				const u32 cd = (dist - 1u) | ((val - 3u) << 15); // the parked match
-				if (ri + 2u < OTZ_RING) {
-					L.ring[ri] = (u8)cd;
-					L.ring[ri + 1u] = (u8) (cd >> 8);
-					L.ring[ri + 2u] = (u8) (cd >> 16);
-				} else {
-					L.ring[ri] = (u8)cd;
-					L.ring[OTZ_RWRAP (ri + 1u)] = (u8) (cd >> 8);
-					L.ring[OTZ_RWRAP (ri + 2u)] = (u8) (cd >> 16);
-				}
+				L.rbuf[ri] = (u8)cd;
+				L.rbuf[ri + 1u] = (u8) (cd >> 8);
+				L.rbuf[ri + 2u] = (u8) (cd >> 16);
 				k3 = otz_alignbit (k3, k2, 16);
 				k2 = otz_alignbit (k2, k1, 16);
 				k1 = otz_alignbit (k1, k0, 16);
-				k0 = (k0 << 16) | rel;
+				k0 = (k0 << 16) | ri;
 				nm += 1u;
-				rel += val;
-				ri = OTZ_RWRAP (ri + val);
+				ri += val;
 				pos += used + dl + dxb;
 			} else {
 				err = 1;
@@ -130,65 +165,73 @@ OTZ_DEV u32 otz_place_items(otz_inflate_lds &L, bool active, u32 s_bit, u32 e_bi
 // stretches that are already final; the others wait for exactly the bytes they need: each
 // step copies up to 16 bytes once the per-byte final bits of THOSE source bytes are set (two
 // bitmap words and the 16 source bytes in one LDS round trip), then sets the bits of what it
-// wrote.  The earliest unresolved match of the round is some lane's current one and never
-// waits, so the loop cannot stall; it is closed by ballots (a convergent exit keeps the waiting lanes and the
-// lanes they wait for in the same loop -- see otz_resolve in otz_inflate.h).
+// wrote.  A source before rbuf[0] is read from the entry's output in global memory: those
+// bytes were final, and stored, before the round began.  The earliest unresolved match of the
+// round is some lane's current one and never waits, so the loop cannot stall; it is closed by
+// ballots (a convergent exit keeps the waiting lanes and the lanes they wait for in the same
+// loop -- see otz_resolve in otz_inflate.h).
 // An overlapping match (distance < 16) copies one period, then two, four, ...
-OTZ_DEV void otz_resolve_list(otz_inflate_lds &L, const otz_job &J, u32 round_base, const u16 *list, u32 n_matches) {
-	constexpr u32 FIN_WORDS = OTZ_RMAX / 32u;
-	const u32 rb = OTZ_RIDX (round_base);
+OTZ_DEV void otz_resolve_list(otz_apply_lds &L, const otz_job &J, u32 p0, const u16 *list, u32 n_matches) {
 	u32 m = otz_tid (); // this lane's next match
-	u32 pend = 0, pdist = 1, o = 0, ri = 0, si = 0;
+	u32 pend = 0, pdist = 1, o = 0;
+	int si = 0; // buffer position of the source; negative: before the buffer
 	u32 spins = 0;
 	for (;;) {
 		OTZ_COUNT (L, J, OTZ_P_B_ITERS, 1);
 		if (pend == 0 && m < n_matches) {
 			// ---- next match of this lane: its parked descriptor
-			const u32 at = list[m];
-			const u32 ai = OTZ_RWRAP (rb + at);
-			u32 cd;
-			if (ai + 3u > OTZ_RING) {
-				cd = (u32)L.ring[ai] | ((u32)L.ring[OTZ_RWRAP (ai + 1u)] << 8) | ((u32)L.ring[OTZ_RWRAP (ai + 2u)] << 16);
-			} else {
-				const u64 dw = otz_ld64u (&L.ring[ai & ~3u]); // (may read past the ring's end: still inside the LDS block)
-				cd = otz_alignbyte ((u32) (dw >> 32), (u32)dw, ai) & 0xFFFFFFu;
-			}
+			o = list[m];
+			const u64 dw = otz_ld64u (&L.rbuf[o & ~3u]);
+			const u32 cd = otz_alignbyte ((u32) (dw >> 32), (u32)dw, o) & 0xFFFFFFu;
 			pdist = (cd & 0x7FFFu) + 1u;
 			pend = (cd >> 15) + 3u;
-			o = at;
-			ri = ai;
-			si = ai >= pdist ? ai - pdist : ai + OTZ_RING - pdist;
+			si = (int)o - (int)pdist;
 			m += OTZ_NT;
 		}
-		// ---- one step: up to 16 bytes that neither overlap their own source nor cross the ring's end
+		// ---- one step: up to 16 bytes that neither overlap their own source nor straddle rbuf[0]
 		u32 n = pend < 16u ? pend : 16u;
 		n = n < pdist ? n : pdist;
-		n = n < OTZ_RING - ri ? n : OTZ_RING - ri;
-		n = n < OTZ_RING - si ? n : OTZ_RING - si;
-		// their source, round-relative [a, b); what lies before the round is final
-		const int so = (int)o - (int)pdist;
-		const u32 a = so < 0 ? 0u : (u32)so;
-		const int be = so + (int)n;
-		const u32 b = be < 0 ? 0u : (u32)be;
-		const u32 w0 = a >> 5 < FIN_WORDS - 1u ? a >> 5 : FIN_WORDS - 2u; // (b - a <= 16 bits: words w0, w0 + 1 hold them)
-		const u64 have = otz_ld64u (&L.fin[w0]);
+		const bool far = si < 0;
+		if (far) {
+			n = n < (u32)-si ? n : (u32)-si;
+		}
+		const u32 a = far ? 0u : (u32)si;
+		const u32 b = far ? 0u : (u32)si + n;
+		const u64 have = otz_ld64u (&L.fin[a >> 5]); // (b - a <= 16 bits: words a/32 and a/32 + 1 hold them)
 		otz_order_loads (); // "flag, then data": the source bytes are read after the bits that declare them final
-		const u64 need = b > a ? (((u64)1 << (b - a)) - 1u) << (a - 32u * w0) : 0u;
+		const u64 need = b > a ? (((u64)1 << (b - a)) - 1u) << (a & 31u) : 0u;
 		const bool go = pend != 0 && (have & need) == need;
 		if (go) {
-			// the source bytes: dword-aligned reads, then a byte funnel shift (reads past the bytes
-			// used, and past the ring's end, land in the LDS block and are ignored)
-			const u32 *sp = reinterpret_cast<const u32 *> (&L.ring[si & ~3u]);
-			const u64 s01 = otz_ld64u (sp);
-			const u32 s2 = sp[2];
-			const u64 lo = otz_alignbyte ((u32) (s01 >> 32), (u32)s01, si) | ((u64)otz_alignbyte (s2, (u32) (s01 >> 32), si) << 32);
-			u64 hi = 0;
-			if (n > 8u) {
-				const u64 s34 = otz_ld64u (sp + 3);
-				hi = otz_alignbyte ((u32)s34, s2, si) | ((u64)otz_alignbyte ((u32) (s34 >> 32), (u32)s34, si) << 32);
+			// the source bytes: dword-aligned reads, then a byte funnel shift (LDS reads past the bytes
+			// used land in the buffer's slack and are ignored)
+			u32 s0, s1, s2, s3 = 0, s4 = 0;
+			if (far) {
+				const u8 *g = J.out + (p0 + (u32)si); // (p0 + si >= 0: the distance was checked against the position)
+				const u32 *gp = reinterpret_cast<const u32 *> ((uintptr_t)g & ~(uintptr_t)3);
+				// only the words that hold bytes of the source: those lie before p0, inside the entry's output
+				const u32 span = ((u32) (uintptr_t)g & 3u) + n; // 1..19
+				s0 = gp[0];
+				s1 = span > 4u ? gp[1] : 0u;
+				s2 = span > 8u ? gp[2] : 0u;
+				s3 = span > 12u ? gp[3] : 0u;
+				s4 = span > 16u ? gp[4] : 0u;
+			} else {
+				const u32 *sp = reinterpret_cast<const u32 *> (&L.rbuf[(u32)si & ~3u]);
+				const u64 s01 = otz_ld64u (sp);
+				s0 = (u32)s01;
+				s1 = (u32) (s01 >> 32);
+				s2 = sp[2];
+				if (n > 8u) {
+					const u64 s34 = otz_ld64u (sp + 3);
+					s3 = (u32)s34;
+					s4 = (u32) (s34 >> 32);
+				}
 			}
+			const u32 q = far ? (u32) ((uintptr_t) (J.out + (p0 + (u32)si)) & 3u) : (u32)si & 3u;
+			const u64 lo = otz_alignbyte (s1, s0, q) | ((u64)otz_alignbyte (s2, s1, q) << 32);
+			const u64 hi = otz_alignbyte (s3, s2, q) | ((u64)otz_alignbyte (s4, s3, q) << 32);
 			// an unaligned 2-byte store is cheap, an unaligned 4-byte store costs three of them
-			u8 *dst = &L.ring[ri];
+			u8 *dst = &L.rbuf[o];
 			u64 v = lo;
 			if (n & 16u) {
 				otz_st64u (dst, lo);
@@ -221,17 +264,19 @@ OTZ_DEV void otz_resolve_list(otz_inflate_lds &L, const otz_job &J, u32 round_ba
 				otz_lds_or (&L.fin[(o >> 5) + 1u], (u32) (mask >> 32));
 			}
 			o += n;
-			ri = OTZ_RWRAP (ri + n);
 			pend -= n;
 			// a whole period written: same source, twice the reach; otherwise the source slides along
 			const bool dbl = n == pdist && pdist < 16u;
-			si = dbl ? si : OTZ_RWRAP (si + n);
+			si += dbl ? 0 : (int)n;
 			pdist += dbl ? n : 0u;
 		}
 		if (J.prof) { // diagnostics: lanes that copied / lanes that had a match in hand, this iteration (wavefront 0)
 			const u32 ng = otz_popc64 (otz_ballot (go)), np = otz_popc64 (otz_ballot (go || pend != 0));
 			OTZ_COUNT (L, J, 11, ng);
 			OTZ_COUNT (L, J, 0, np);
+			const u32 nf = otz_popc64 (otz_ballot (go && far));
+			OTZ_COUNT (L, J, 4, nf);
+			OTZ_COUNT (L, J, 5, nf ? 1u : 0u);
 		}
 		if (otz_ballot (pend != 0 || m < n_matches) == 0) {
 			break;
@@ -245,7 +290,7 @@ OTZ_DEV void otz_resolve_list(otz_inflate_lds &L, const otz_job &J, u32 round_ba
 				if (spins > OTZ_SPIN_LIMIT) {
 					L.dbg[0] = 3; // waited too long for source bytes
 					L.dbg[1] = otz_tid ();
-					L.dbg[2] = round_base + o;
+					L.dbg[2] = p0 + o;
 					L.dbg[3] = pdist | (pend << 16);
 					otz_set_status (L, OZG_ST_INTERNAL);
 					break;
@@ -255,9 +300,108 @@ OTZ_DEV void otz_resolve_list(otz_inflate_lds &L, const otz_job &J, u32 round_ba
 	}
 }
 
-// All OTZ_NT work-items.  Work-item 0 writes *res.
+// ---------------------------------------------------------------- rounds
+//
+// Stage the round's compressed bytes: n_bytes from in + byte0, from the 16-byte-aligned address
+// at or below it (otz_stage_load, but only the chunks the round reads: one load per lane, not two).
+OTZ_DEV void otz_a_stage(otz_apply_lds &L, const otz_job &J, u32 byte0, u32 n_bytes) {
+	const u8 *p = J.in + byte0;
+	const u32 skew = (u32) ((uintptr_t)p & 15u);
+	const u8 *ga = p - skew;
+	const u8 *lo = J.in, *hi = J.in + J.n_in;
+	u32 chunks = (skew + n_bytes + 15u) >> 4;
+	chunks = chunks < OTZ_STAGE_BYTES / 16u ? chunks : OTZ_STAGE_BYTES / 16u;
+	for (u32 c = otz_tid (); c < chunks; c += OTZ_NT) {
+		const u8 *a = ga + 16u * c;
+		otz_u4 v;
+		if (a >= lo && a + 16 <= hi) {
+			v = otz_ld16_aligned (a);
+		} else {
+			u32 w[4] = { 0, 0, 0, 0 };
+			if (a + 16 > lo && a < hi) {
+				for (u32 k = 0; k < 16; k++) {
+					const u8 *q = a + k;
+					if (q >= lo && q < hi) {
+						w[k >> 2] |= (u32)*q << (8u * (k & 3u));
+					}
+				}
+			}
+			v.x = w[0];
+			v.y = w[1];
+			v.z = w[2];
+			v.w = w[3];
+		}
+		u32 *d = &L.stage_w[4u * c];
+		d[0] = v.x;
+		d[1] = v.y;
+		d[2] = v.z;
+		d[3] = v.w;
+	}
+}
+
+//
+// Start of a round: nothing after the decoded bytes is final.  (ll shares the bitmap's storage.)
+OTZ_DEV void otz_a_begin(otz_apply_lds &L, const otz_a_pos &P) {
+	const u32 h = P.opos - P.p0;
+	for (u32 i = otz_tid (); i < OTZ_A_FIN_WORDS; i += OTZ_NT) {
+		L.fin[i] = i < h >> 5 ? 0xFFFFFFFFu : i == h >> 5 ? (1u << (h & 31u)) - 1u : 0u;
+	}
+}
+
+// End of a round that decoded `produced` bytes (all final, a barrier passed): store the whole
+// 16-byte chunks not yet in global memory, then slide the buffer so that it starts OTZ_A_WIN
+// bytes (rounded down to a chunk) before the end.  All work-items; ends with a barrier.
+OTZ_DEV void otz_a_advance(otz_apply_lds &L, const otz_job &J, otz_a_pos &P, u32 produced) {
+	const u32 tid = otz_tid ();
+	const u32 end = P.opos + produced;
+	const u32 up = end & ~15u;
+	for (u32 c = tid; c < (up - P.flushed) >> 4; c += OTZ_NT) {
+		otz_st16_aligned (J.out + P.flushed + 16u * c, otz_ld16_aligned (&L.rbuf[P.flushed - P.p0 + 16u * c]));
+	}
+	P.flushed = up;
+	P.opos = end;
+	const u32 keep = up > OTZ_A_WIN ? up - OTZ_A_WIN : 0u;
+	if (keep > P.p0) {
+		constexpr u32 CH = (OTZ_A_WIN / 16u + 1u + OTZ_NT - 1u) / OTZ_NT;
+		const u32 d = keep - P.p0, chunks = (end - keep + 15u) >> 4;
+		otz_u4 t[CH];
+#pragma unroll
+		for (u32 k = 0; k < CH; k++) {
+			const u32 c = tid + k * OTZ_NT;
+			if (c < chunks) {
+				t[k] = otz_ld16_aligned (&L.rbuf[d + 16u * c]);
+			}
+		}
+		otz_sync ();
+#pragma unroll
+		for (u32 k = 0; k < CH; k++) {
+			const u32 c = tid + k * OTZ_NT;
+			if (c < chunks) {
+				otz_st16_aligned (&L.rbuf[16u * c], t[k]);
+			}
+		}
+		P.p0 = keep;
+	}
+	otz_sync ();
+}
+
+// The last, partial chunk.  All work-items.
+OTZ_DEV void otz_a_finish(otz_apply_lds &L, const otz_job &J, otz_a_pos &P) {
+	const u32 tid = otz_tid ();
+	if (tid < P.opos - P.flushed) {
+		J.out[P.flushed + tid] = L.rbuf[P.flushed - P.p0 + tid];
+	}
+	P.flushed = P.opos;
+}
+
+// Output byte at position p, wherever it lives.
+OTZ_DEV u8 otz_a_byte(const otz_apply_lds &L, const otz_job &J, const otz_a_pos &P, u32 p) {
+	return p < P.p0 ? J.out[p] : L.rbuf[p - P.p0];
+}
+
+// All OTZ_NT work-items.  Work-item 0 writes *res (crc32 and the CRC flag are left to the CRC pass).
 // end_bit (optional): where the stream ended, for the z_stream seam's total_in.
-OTZ_DEV void otz_apply_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_crc, const otz_ix_head *head, const u8 *region, ozg_result *res, u64 *end_bit) {
+OTZ_DEV void otz_apply_entry(otz_apply_lds &L, const otz_job &J, const otz_ix_head *head, const u8 *region, ozg_result *res, u64 *end_bit) {
 	const u32 tid = otz_tid ();
 	const int hst = head->status;
 	if (hst == OTZ_IX_OVERFLOW) {
@@ -276,8 +420,7 @@ OTZ_DEV void otz_apply_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_cr
 		}
 		return;
 	}
-	u32 opos = 0, flushed = 0;
-	u32 crc_reg = 0xFFFFFFFFu;
+	otz_a_pos P = { 0, 0, 0 };
 	u32 flags = head->flags;
 	const u32 n_blocks = head->n_blocks;
 	if (tid == 0) {
@@ -299,7 +442,7 @@ OTZ_DEV void otz_apply_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_cr
 		const u32 hlit = blk->hlit_hdist & 0xFFFFu, hdist = blk->hlit_hdist >> 16;
 		const u32 next = blk->next;
 		OTZ_COUNT (L, J, OTZ_P_BLOCKS, 1);
-		if (blk->out_base != opos) {
+		if (blk->out_base != P.opos) {
 			otz_fail_all (L, OZG_ST_INTERNAL);
 			break;
 		}
@@ -307,24 +450,22 @@ OTZ_DEV void otz_apply_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_cr
 			const u32 src_byte = blk->bit_lo;
 			u32 done = 0;
 			while (done < out_len) {
-				u32 n = out_len - done;
-				if (n > OTZ_RMAX) {
-					n = OTZ_RMAX;
+				const u32 n = out_len - done < OTZ_A_RMAX ? out_len - done : OTZ_A_RMAX;
+				const u32 h = P.opos - P.p0;
+				for (u32 i = tid; i < n; i += OTZ_NT) {
+					L.rbuf[h + i] = J.in[src_byte + done + i];
 				}
-				otz_make_room (L, J, opos, n, flushed, crc_reg);
-				otz_copy_in (L, J, src_byte + done, opos, n);
-				opos += n;
-				done += n;
 				otz_sync ();
+				otz_a_advance (L, J, P, n);
+				done += n;
 			}
 			OTZ_MARK (L, J, OTZ_P_STORED);
 			boff = next;
 			continue;
 		}
 		// ---- Huffman block: tables from the stored code lengths
-		otz_sync (); // (ll shares its storage with the final bitmap of the previous block's last round)
-		for (u32 i = tid; i < OTZ_IX_LENS; i += OTZ_NT) {
-			L.ll[i] = region[boff + 32u + i];
+		if (tid < OTZ_IX_LENS) {
+			L.ll[tid] = region[boff + 32u + tid];
 		}
 		otz_sync ();
 		if (!otz_build_tables (L, hlit, hdist)) {
@@ -335,7 +476,6 @@ OTZ_DEV void otz_apply_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_cr
 		const otz_ix_item *items = reinterpret_cast<const otz_ix_item *> (region + boff + OTZ_IX_ITEMS_OFF);
 		u32 base = 0;
 		while (base < n_items) {
-			otz_make_room (L, J, opos, OTZ_RMAX, flushed, crc_reg);
 			// ---- how many items this round takes
 			const u32 ia = base + tid < n_items ? base + tid : n_items;
 			const u32 ib = ia < n_items ? ia + 1u : n_items;
@@ -347,43 +487,51 @@ OTZ_DEV void otz_apply_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_cr
 			const u32 p0 = skew * 8u + (u32) (abs0 & 7u);
 			// a walk reads up to five words past the one holding its position
 			const u32 bit_room = 8u * OTZ_STAGE_BYTES - 192u - p0;
-			const bool fits = base + tid < n_items && z.out - first.out <= OTZ_RMAX && z.bit - first.bit <= bit_room && z.out >= a.out && z.bit >= a.bit;
+			const bool fits = base + tid < n_items && z.out - first.out <= OTZ_A_RMAX && z.bit - first.bit <= bit_room && z.out >= a.out && z.bit >= a.bit;
 			if (tid == 0) {
 				L.first_rej = OTZ_NT;
+				L.flag = 0;
 			}
 			otz_sync ();
 			otz_wave_min_tid (&L.first_rej, !fits);
+			{ // how far the round's bits reach (bounds the staging): the last fitting lane of each wavefront knows
+				const u64 fm = otz_ballot (fits);
+				if (fm != 0 && otz_lane () == 63u - otz_clz64 (fm)) {
+					otz_lds_max (&L.flag, z.bit - first.bit);
+				}
+			}
 			otz_sync ();
 			const u32 n = L.first_rej;
-			if (n == 0 || blk->out_base + first.out != opos) {
+			const u32 span_bits = L.flag;
+			if (n == 0 || blk->out_base + first.out != P.opos) {
 				otz_fail_all (L, OZG_ST_INTERNAL);
 				break;
 			}
-			(void)otz_stage_load (L, J, byte0);
-			for (u32 i = tid; i < OTZ_RMAX / 32; i += OTZ_NT) {
-				L.fin[i] = 0;
+			if (tid + 1u == n) {
+				L.last_out = z.out; // (read after the barriers of otz_place_items)
 			}
+			otz_a_stage (L, J, byte0, (((u32)abs0 & 7u) + span_bits + 7u) / 8u + 24u);
+			otz_a_begin (L, P);
 			otz_sync ();
 			OTZ_MARK (L, J, OTZ_P_STAGE);
 			OTZ_COUNT (L, J, OTZ_P_ROUNDS, 1);
-			const u32 last_out = items[base + n].out;
-			const u32 produced = last_out - first.out;
 			const u32 s_bit = p0 + (a.bit - first.bit), e_bit = p0 + (z.bit - first.bit);
 			// the match list takes over the stage buffer once every lane has read its tokens
 			u16 *const list = reinterpret_cast<u16 *> (L.stage);
-			const u32 n_matches = otz_place_items (L, tid < n, s_bit, e_bit, opos + (a.out - first.out), opos, list);
+			const u32 n_matches = otz_place_items (L, tid < n, s_bit, e_bit, P.opos - P.p0 + (a.out - first.out), P.p0, list);
 			otz_sync ();
 			OTZ_MARK (L, J, OTZ_P_EMIT);
 			if (otz_get_status (L) != 0) {
 				break;
 			}
-			otz_resolve_list (L, J, opos, list, n_matches);
+			otz_resolve_list (L, J, P.p0, list, n_matches);
 			otz_sync ();
 			OTZ_MARK (L, J, OTZ_P_RESOLVE);
 			if (otz_get_status (L) != 0) {
 				break;
 			}
-			opos += produced;
+			otz_a_advance (L, J, P, L.last_out - first.out);
+			OTZ_MARK (L, J, OTZ_P_FLUSH);
 			base += n;
 		}
 		boff = next;
@@ -393,7 +541,7 @@ OTZ_DEV void otz_apply_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_cr
 	if (J.prof && tid == 0) {
 		L.prof[OTZ_P_TOTAL] += otz_cycles ();
 	}
-	if (status == 0 && opos != head->total_out) {
+	if (status == 0 && P.opos != head->total_out) {
 		status = OZG_ST_INTERNAL;
 	}
 	if (status == 0 && need_out) {
@@ -402,34 +550,32 @@ OTZ_DEV void otz_apply_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_cr
 		// written, the entry reports OZG_ST_NEED_OUT.  (The tables of the last block are still up.)
 		const u64 clip = ((u64)head->clip_hi << 32) | head->clip_lo;
 		const u32 byte0 = (u32) (clip >> 3);
-		otz_make_room (L, J, opos, 512u, flushed, crc_reg);
-		otz_sync ();
 		const u32 skew = otz_stage_load (L, J, byte0);
 		otz_sync ();
 		const u32 p = skew * 8u + (u32) (clip & 7u);
 		const u32 w = p >> 5;
 		const otz_tok t = otz_decode_bits (L, otz_alignbit (L.stage_w[w + 1u], L.stage_w[w], p), otz_alignbit (L.stage_w[w + 2u], L.stage_w[w + 1u], p));
-		const u32 room = J.out_cap - opos;
+		const u32 room = J.out_cap - P.opos;
 		u32 n = 0;
 		if (t.kind == OTZ_K_LEN) {
-			if (t.dist > opos) {
+			if (t.dist > P.opos) {
 				status = OZG_ST_DATA;
 			} else {
 				n = t.val < room ? t.val : room;
 				if (tid == 0) {
 					for (u32 i = 0; i < n; i++) { // (byte by byte: the copy may overlap itself)
-						L.ring[OTZ_RIDX (opos + i)] = L.ring[OTZ_RIDX (opos + i - t.dist)];
+						L.rbuf[P.opos - P.p0 + i] = otz_a_byte (L, J, P, P.opos + i - t.dist);
 					}
 				}
 			}
 		}
 		otz_sync ();
 		if (status == 0) {
-			opos += n;
-			otz_flush (L, J, flushed, opos, crc_reg);
+			otz_a_advance (L, J, P, n);
+			otz_a_finish (L, J, P);
 			if (tid == 0) {
 				res->status = OZG_ST_NEED_OUT;
-				res->total_out = opos;
+				res->total_out = P.opos;
 				res->crc32 = 0;
 				res->flags = 0;
 			}
@@ -437,42 +583,41 @@ OTZ_DEV void otz_apply_entry(otz_inflate_lds &L, const otz_job &J, u32 expect_cr
 		}
 	}
 	if (status == 0) {
-		const u32 produced = opos;
-		if (opos < J.out_cap) {
+		const u32 produced = P.opos;
+		otz_a_finish (L, J, P);
+		if (produced < J.out_cap) {
 			// short stream, zero-filled tail
 			flags |= OZG_F_SHORT_STREAM;
-			while (opos < J.out_cap) {
-				u32 n = J.out_cap - opos;
-				if (n > OTZ_RMAX) {
-					n = OTZ_RMAX;
-				}
-				otz_make_room (L, J, opos, n, flushed, crc_reg);
-				otz_sync ();
-				otz_fill_zero (L, opos, n);
-				opos += n;
-				otz_sync ();
+			const u32 a16 = (produced + 15u) & ~15u;
+			const u32 head_end = a16 < J.out_cap ? a16 : J.out_cap;
+			if (produced + tid < head_end) {
+				J.out[produced + tid] = 0;
 			}
-		}
-		otz_flush (L, J, flushed, opos, crc_reg);
-		const u32 crc = ~crc_reg;
-		if (crc != expect_crc) {
-			flags |= OZG_F_CRC_MISMATCH;
+			const otz_u4 zero = { 0, 0, 0, 0 };
+			u32 c = a16 + 16u * tid;
+			for (; c + 16u <= J.out_cap; c += 16u * OTZ_NT) {
+				otz_st16_aligned (J.out + c, zero);
+			}
+			if (c < J.out_cap) { // (one work-item: the partial chunk at the very end)
+				for (; c < J.out_cap; c++) {
+					J.out[c] = 0;
+				}
+			}
 		}
 		if (tid == 0) {
 			res->status = OZG_ST_OK;
 			res->total_out = produced;
-			res->crc32 = crc;
+			res->crc32 = 0;
 			res->flags = flags;
 		}
 		if (J.prof && tid == 0) {
-			L.prof[OTZ_P_FLUSH] += otz_cycles () - L.prof_last;
 			for (u32 i = 0; i < 16; i++) {
 				J.prof[i] = L.prof[i];
 			}
 		}
 	} else if (tid == 0) {
 		res->status = status;
-		res->total_out = status == OZG_ST_INTERNAL ? L.dbg[1] : opos;
+		res->total_out = status == OZG_ST_INTERNAL ? L.dbg[1] : P.opos;
 		res->crc32 = status == OZG_ST_INTERNAL ? L.dbg[2] : 0;
 		res->flags = status == OZG_ST_INTERNAL ? (L.dbg[0] << 28) | (L.dbg[3] & 0x0FFFFFFF) : 0;
 	}

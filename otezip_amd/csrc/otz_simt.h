@@ -157,6 +157,8 @@ OTZ_DEV void otz_order_stores() { asm volatile ("" ::: "memory"); }
 OTZ_DEV void otz_touch64(u64 &v) { asm volatile ("" : "+v"(v)); }
 // Hides a value's origin from the optimiser: stops it from computing per-lane constants
 // once in the kernel prologue and keeping them alive (spilled) across everything else.
+// "Uses" a value without doing anything: the load that produced it has to have returned by here.
+OTZ_DEV void otz_consume(u32 v) { asm volatile ("" ::"v"(v)); }
 OTZ_DEV u32 otz_opaque(u32 v) {
 	asm volatile ("" : "+v"(v));
 	return v;

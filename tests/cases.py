@@ -127,6 +127,25 @@ def deflate_ring_wrap(seed=7, ring=57344):
     return out
 
 
+def deflate_far_matches(seed=8, n=6):
+    """Matches whose source lies far back (up to the full 32 KiB window): the apply kernel keeps only
+    the last few KiB before the round in LDS and reads older bytes from the entry's own output in
+    global memory -- at every alignment, with lengths 3..258, and next to fresh literals."""
+    r = _rng(seed)
+    out = []
+    for k in range(n):
+        d = bytearray(word_text(r, 30000 + 997 * k))
+        while len(d) < 90000 + 5000 * k:
+            back = r.randrange(1, min(len(d), 32768 - 300))
+            ln = r.choice((3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 33, 64, 100, 257, 258))
+            at = len(d) - back
+            d += d[at:at + ln] if back >= ln else (d[at:] * (ln // back + 1))[:ln]
+            d += bytes(r.randrange(256) for _ in range(r.randrange(0, 4)))
+        d = bytes(d)
+        out.append((8, raw_deflate(d), len(d), crc(d), 0))
+    return out
+
+
 def containers(seed=6):
     """STORE and the private framings of methods 93/100/97/14, good and bad."""
     r = _rng(seed)

@@ -80,6 +80,7 @@ def emu_lib():
         L.emu_lds_bytes_index.restype = C.c_uint32
         L.emu_lds_bytes_inflate.restype = C.c_uint32
         L.emu_lds_bytes_copy.restype = C.c_uint32
+        L.emu_lds_bytes_apply.restype = C.c_uint32
         _emu = L
     return _emu
 

@@ -79,17 +79,18 @@ void *thread_main(void *p) {
 		otz_crc_load_slice4 (L.t4);
 		otz_crc_load_adv4k (L.a4);
 		otz_sync ();
-		const u32 m = a->r->total_out;
-		const u32 R = otz_stream_crc (L, a->dst + a->e->dst_off, nullptr, m, false);
-		if (otz_tid () == 0) {
-			const u32 crc = ~(otz_gf_mul (0xFFFFFFFFu, otz_xpow_bytes (m)) ^ R);
-			a->r->crc32 = crc;
-			a->r->flags = crc != a->e->crc32 ? OZG_F_CRC_MISMATCH : 0u;
-		}
+		otz_run_crc (L, a->dst, *a->e, a->r, a->r->total_out, false);
+	} else if (a->phase == 7) {
+		// what otz_out_crc_kernel does
+		otz_copy_lds &L = *(otz_copy_lds *)a->lds;
+		otz_crc_load_slice4 (L.t4);
+		otz_crc_load_adv4k (L.a4);
+		otz_sync ();
+		otz_run_crc (L, a->dst, *a->e, a->r, a->e->uncomp_size, true);
 	} else if (a->phase == 1) {
 		otz_run_index<false> (*(otz_k1_lds *)a->lds, a->src, a->dst, *a->e, a->lim, a->head, a->region, a->region_bytes);
 	} else if (a->phase == 2) {
-		otz_run_apply (*(otz_inflate_lds *)a->lds, a->src, a->dst, *a->e, a->r, a->lim, a->head, a->region, nullptr, a->end_bit);
+		otz_run_apply (*(otz_apply_lds *)a->lds, a->src, a->dst, *a->e, a->r, a->lim, a->head, a->region, nullptr, a->end_bit);
 	} else if (a->e->method == OZG_METHOD_DEFLATE) {
 		otz_run_inflate (*(otz_inflate_lds *)a->lds, a->src, a->dst, *a->e, a->r, a->lim, nullptr);
 	} else {
@@ -296,7 +297,7 @@ extern "C" int emu_decode_batch_mode(const void *src, uint64_t src_len, void *ds
 		memset (&head, 0xA5, sizeof (head));
 		u64 want = mode == 2 ? 0 : otz_ix_region_bytes (entries[i].comp_size, entries[i].uncomp_size) * region_scale_pct / 100u;
 		want &= ~(u64)255u;
-		std::vector<u8> region (want + 64, 0xA5);
+		std::vector<u8> region (want + 512, 0xA5);
 		a.head = &head;
 		a.end_bit = g_end_bits ? g_end_bits + i : nullptr;
 		a.region = region.data ();
@@ -304,7 +305,11 @@ extern "C" int emu_decode_batch_mode(const void *src, uint64_t src_len, void *ds
 		a.phase = 1;
 		run_block (64, a, sizeof (otz_k1_lds));
 		a.phase = 2;
-		run_block (OTZ_NT, a, lds_bytes);
+		run_block (OTZ_NT, a, sizeof (otz_apply_lds));
+		if (results[i].status == OZG_ST_OK) {
+			a.phase = 7;
+			run_block (OTZ_CNT, a, lds_bytes);
+		}
 		if (head.status == OTZ_IX_OVERFLOW) { // what otz_inflate_kernel does with the overflow list
 			a.phase = 0;
 			run_block (OTZ_NT, a, lds_bytes);
@@ -320,6 +325,7 @@ extern "C" int emu_decode_batch(const void *src, uint64_t src_len, void *dst, ui
 
 extern "C" uint32_t emu_lds_bytes_index(void) { return (uint32_t)sizeof (otz_k1_lds); }
 extern "C" uint32_t emu_lds_bytes_inflate(void) { return (uint32_t)sizeof (otz_inflate_lds); }
+extern "C" uint32_t emu_lds_bytes_apply(void) { return (uint32_t)sizeof (otz_apply_lds); }
 extern "C" uint32_t emu_lds_bytes_copy(void) { return (uint32_t)sizeof (otz_copy_lds); }
 extern "C" uint32_t emu_lds_bytes_zstd(void) { return (uint32_t)sizeof (otz_zs_lds); }
 

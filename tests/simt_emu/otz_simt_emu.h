@@ -222,6 +222,7 @@ OTZ_DEV void otz_st16u(void *p, u16 v) { memcpy (p, &v, 2); }
 OTZ_DEV void otz_order_loads() { __atomic_thread_fence (__ATOMIC_ACQUIRE); }
 OTZ_DEV void otz_order_stores() { __atomic_thread_fence (__ATOMIC_RELEASE); }
 OTZ_DEV void otz_touch64(u64 &v) { (void)v; }
+OTZ_DEV void otz_consume(u32 v) { (void)v; }
 OTZ_DEV u32 otz_opaque(u32 v) { return v; }
 
 OTZ_DEV otz_u4 otz_ld16(const void *p) {

@@ -16,6 +16,7 @@ def _run(items):
 
 def test_lds_budget_allows_two_workgroups_per_cu():
     assert emu_lib().emu_lds_bytes_inflate() <= 80 * 1024
+    assert emu_lib().emu_lds_bytes_apply() <= 160 * 1024 // 4  # four apply workgroups per CU
     assert emu_lib().emu_lds_bytes_copy() <= 16 * 1024
     assert emu_lib().emu_lds_bytes_index() <= 8 * 1024  # twenty index wavefronts per CU
 
@@ -59,6 +60,10 @@ def test_deflate_beyond_the_lds_ring():
 
 def test_deflate_overlapping_matches_across_the_ring_end():
     _run(cases.deflate_ring_wrap())
+
+
+def test_deflate_matches_reaching_behind_the_lds_window():
+    _run(cases.deflate_far_matches(n=3))
 
 
 def test_containers():

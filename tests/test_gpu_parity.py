@@ -45,7 +45,7 @@ def assert_parity(items, b, what):
     return n_ok, n_f2
 
 
-@pytest.mark.parametrize("name", ["deflate_valid", "deflate_tiny_f2", "deflate_edge", "deflate_fuzz", "deflate_large", "deflate_ring_wrap",
+@pytest.mark.parametrize("name", ["deflate_valid", "deflate_tiny_f2", "deflate_edge", "deflate_fuzz", "deflate_large", "deflate_ring_wrap", "deflate_far_matches",
                                   "containers"])
 def test_parity_vs_oracle(gpu_lib, name):
     items = getattr(cases, name)()
