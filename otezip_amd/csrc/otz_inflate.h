@@ -458,11 +458,17 @@ OTZ_DEV bool otz_canon_build(otz_canon &c, const u32 *hist) {
 // among the symbols of the same length, and the rank comes from wavefront ballots --
 // no sorted symbol list is ever materialised.  The symbol then writes its own root
 // slots (code no longer than the root), or claims a sub-table under its root slot.
+#ifdef OTZ_TB_PROF
+#define OTZ_TBMARK(slot) do { if (otz_tid () == 0) { u64 _t = otz_cycles (); L.prof[slot] += _t - L.prof_last; L.prof_last = _t; } } while (0)
+#else
+#define OTZ_TBMARK(slot) do { } while (0)
+#endif
 template <class LDS>
 OTZ_DEV bool otz_build_tables(LDS &L, u32 hlit, u32 hdist) {
 	static_assert (OTZ_NT >= 384 && OTZ_NT >= (1u << OTZ_LIT_ROOT), "one work-item per symbol and per literal root slot");
 	constexpr u32 LRSZ = 1u << OTZ_LIT_ROOT, DRSZ = 1u << OTZ_DIST_ROOT;
-	const u32 tid = otz_opaque (otz_tid ()), lane = otz_lane (), wave = otz_wave ();
+	// (opaque: nothing derived from them is computed once before the caller's block loop and kept -- spilled -- across it)
+	const u32 tid = otz_opaque (otz_tid ()), lane = otz_opaque (otz_lane ()), wave = otz_opaque (otz_wave ());
 	const bool is_dist = tid >= 320u;
 	const u32 sym = is_dist ? tid - 320u : tid;
 	u32 l = 0;
@@ -491,6 +497,7 @@ OTZ_DEV bool otz_build_tables(LDS &L, u32 hlit, u32 hdist) {
 		}
 	}
 	otz_sync ();
+	OTZ_TBMARK (1);
 	// Canonical bookkeeping, one lane per code length (wavefront 0: literal/length code,
 	// wavefront 1: distance code): first[l] = sum over j < l of count[j] << (l - j),
 	// off[l] = sum over j < l of count[j].  A set is over-subscribed (ref: "left < 0")
@@ -525,6 +532,7 @@ OTZ_DEV bool otz_build_tables(LDS &L, u32 hlit, u32 hdist) {
 		}
 	}
 	otz_sync ();
+	OTZ_TBMARK (6);
 	if (L.flag == 0u || L.first_rej == 0u) {
 		return false;
 	}
@@ -549,6 +557,7 @@ OTZ_DEV bool otz_build_tables(LDS &L, u32 hlit, u32 hdist) {
 		}
 	}
 	otz_sync ();
+	OTZ_TBMARK (9);
 	// sub-table placement: one prefix sum over the root slots of both tables (literal
 	// sizes in the low half of the scanned word, distance sizes in the high half)
 	u32 el = L.lit_lut[tid < LRSZ ? tid : 0u], ed = L.dist_lut[tid < DRSZ ? tid : 0u];
@@ -567,6 +576,7 @@ OTZ_DEV bool otz_build_tables(LDS &L, u32 hlit, u32 hdist) {
 		}
 	}
 	otz_sync ();
+	OTZ_TBMARK (5);
 	if (!fits) {
 		return false;
 	}

@@ -311,7 +311,7 @@ OTZ_DEV void otz_a_stage(otz_apply_lds &L, const otz_job &J, u32 byte0, u32 n_by
 	const u8 *lo = J.in, *hi = J.in + J.n_in;
 	u32 chunks = (skew + n_bytes + 15u) >> 4;
 	chunks = chunks < OTZ_STAGE_BYTES / 16u ? chunks : OTZ_STAGE_BYTES / 16u;
-	for (u32 c = otz_tid (); c < chunks; c += OTZ_NT) {
+	for (u32 c = otz_opaque (otz_tid ()); c < chunks; c += OTZ_NT) { // (opaque: no per-lane address kept across the rounds)
 		const u8 *a = ga + 16u * c;
 		otz_u4 v;
 		if (a >= lo && a + 16 <= hi) {

@@ -11,7 +11,7 @@ import torch
 import otezip_amd as oz
 from otezip_amd import corpus, _native as N
 
-NAMES = ["res_busy#", "lengths", "tables", "stage", "far_go#", "far_it#", "scan", "place", "flush", "stored", "resolve", "res_go#",
+NAMES = ["res_busy#", "tb_rank", "tables", "stage", "far_go#", "tb_link", "tb_canon", "place", "flush", "tb_root", "resolve", "res_go#",
          "rounds#", "B_iters#", "blocks#", "total"]
 
 
