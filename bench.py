@@ -282,7 +282,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(algo / kavg / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(algo / kavg / HBM_PEAK, 5),
                          "traffic": pmc_traffic(n, args.entry_size, args.method),
-                         "kernel": (N.lib().ozg_kernel_name_index().decode() + "+" + N.lib().ozg_kernel_name_inflate().decode())
+                         "kernel": (N.lib().ozg_kernel_name_index().decode() + "+" + N.lib().ozg_kernel_name_inflate().decode() + "+otz_out_crc_kernel")
                          if args.method == 8 else N.lib().ozg_kernel_name_copy().decode(),
                          "kernel_build_id": kernel_build_id(),
                          "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(kavg * 1e3, 4)},

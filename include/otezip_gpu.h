@@ -124,6 +124,8 @@ int ozg_decode_batch_device(const void *d_src, uint64_t src_len, void *d_dst, ui
                                    * stream behind the APPNOTE 5.8.8 header, or the reference's private token format) */
 #define OZG_BATCH_NO_ZSTD 4u      /* no entry is method 93: skip the Zstandard kernels (a method-93 payload is sniffed:
                                    * a Zstandard frame per RFC 8878, or the reference's private raw-block framing) */
+#define OZG_BATCH_NO_BROTLI 16u   /* no entry is method 97: skip the Brotli kernel (a method-97 payload is sniffed: the
+                                   * reference's "BROT" container, or a Brotli stream per RFC 7932) */
 int ozg_decode_batch_device_ex(const void *d_src, uint64_t src_len, void *d_dst, uint64_t dst_len,
 	const ozg_entry *d_entries, ozg_result *d_results, uint32_t n, void *stream, uint32_t batch_flags);
 

@@ -31,6 +31,9 @@
 #include "otz_deflate_enc.h"
 #include "otz_zstd.h"
 #include "otz_lzma.h"
+#include "otz_brotli.h"
+
+extern "C" const unsigned char otz_brotli_blob[], otz_brotli_blob_end[]; // otezip_amd/data/brotli_rfc7932.bin (brotli_data.S)
 
 static_assert (sizeof (ozg_entry) == 32, "ozg_entry ABI");
 static_assert (sizeof (ozg_result) == 16, "ozg_result ABI");
@@ -224,7 +227,27 @@ otz_lzma_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *re
 	}
 }
 
-// CRC-32 of the entries otz_zstd_kernel / otz_lzma_kernel decoded (ref src/lib/otezip.c:667-679)
+// Brotli streams under method 97 (otz_brotli.h): one work-item per stream, a persistent grid; every work-item
+// owns OTZ_BR_ARENA bytes of scratch for the tables of the meta-block it is in.  blob: brotli_rfc7932.bin.
+extern "C" __global__ void __launch_bounds__ (64)
+otz_brotli_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *results, u32 n, u64 src_len, u64 dst_len, ozg_limits lim,
+	u8 *arena, const u8 *blob, u32 *cursor, u8 *route) {
+	u8 *mine = arena + (size_t) (blockIdx.x * 64u + threadIdx.x) * OTZ_BR_ARENA;
+	for (;;) {
+		const u32 i = atomicAdd (cursor, 1u);
+		if (i >= n) {
+			break;
+		}
+		const ozg_entry e = entries[i];
+		if (e.method != OZG_METHOD_BROTLI || !otz_entry_in_bounds (e, src_len, dst_len) || otz_zipbomb (e, lim) ||
+			!otz_brotli_is_candidate (src + e.src_off, e.comp_size)) {
+			continue; // the copy kernel's (route stays 0)
+		}
+		otz_brotli_run (src + e.src_off, e.comp_size, dst + e.dst_off, e.uncomp_size, mine, blob, &results[i], &route[i]);
+	}
+}
+
+// CRC-32 of the entries otz_zstd_kernel / otz_lzma_kernel / otz_brotli_kernel decoded (ref src/lib/otezip.c:667-679)
 extern "C" __global__ void __launch_bounds__ (256)
 otz_zstd_crc_kernel(u8 *dst, const ozg_entry *entries, ozg_result *results, u32 n, const u8 *route) {
 	extern __shared__ __attribute__ ((aligned (16))) u8 otz_smem[];
@@ -536,6 +559,10 @@ struct workspace {
 	u8 *lz_probs = nullptr;
 	u32 lz_threads = 0;
 	u32 *lz_cursor = nullptr;
+	u8 *br_arena = nullptr; // Brotli: OTZ_BR_ARENA bytes per work-item
+	u32 br_threads = 0;
+	u32 *br_cursor = nullptr;
+	u8 *br_blob = nullptr;  // the RFC's constant data on this device
 	// encode side: token scratch of the persistent grid, its buffer counter
 	u32 *enc_tok = nullptr;
 	u32 enc_grid = 0;
@@ -700,6 +727,9 @@ void ws_free(workspace &ws) {
 	(void)hipFree (ws.zs_route);
 	(void)hipFree (ws.lz_probs);
 	(void)hipFree (ws.lz_cursor);
+	(void)hipFree (ws.br_arena);
+	(void)hipFree (ws.br_cursor);
+	(void)hipFree (ws.br_blob);
 	if (ws.enc_done) {
 		(void)hipEventDestroy (ws.enc_done);
 	}
@@ -787,21 +817,23 @@ int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, 
 	}
 	if (!(batch_flags & OZG_BATCH_ONLY_DEFLATE)) {
 		const u8 *route = nullptr;
-		const bool want_zs = !(batch_flags & OZG_BATCH_NO_ZSTD), want_lz = !(batch_flags & OZG_BATCH_NO_LZMA);
-		if (want_zs || want_lz) {
+		const bool want_zs = !(batch_flags & OZG_BATCH_NO_ZSTD), want_lz = !(batch_flags & OZG_BATCH_NO_LZMA), want_br = !(batch_flags & OZG_BATCH_NO_BROTLI);
+		if (want_zs || want_lz || want_br) {
 			// methods 93 and 14: the real formats first (the rest of the batch, and what turns out not to
 			// be one of them, is the copy kernel's)
 			workspace &ws = C.ws;
 			const u32 grid = n < C.zs_grid ? n : C.zs_grid;
 			const u32 lz_threads = ((n < 32768u ? n : 32768u) + 63u) & ~63u;
+			const u32 br_threads = ((n < 1024u ? n : 1024u) + 63u) & ~63u;
 			if (!ws.done) {
 				OZG_HIP (hipEventCreateWithFlags (&ws.done, hipEventDisableTiming));
 			}
 			if (!ws.zs_cursor) {
 				OZG_HIP (hipMalloc ((void **)&ws.zs_cursor, 256));
 				OZG_HIP (hipMalloc ((void **)&ws.lz_cursor, 256));
+				OZG_HIP (hipMalloc ((void **)&ws.br_cursor, 256));
 			}
-			if ((want_zs && grid > ws.zs_grid) || n > ws.zs_route_cap || (want_lz && lz_threads > ws.lz_threads)) {
+			if ((want_zs && grid > ws.zs_grid) || n > ws.zs_route_cap || (want_lz && lz_threads > ws.lz_threads) || (want_br && br_threads > ws.br_threads)) {
 				OZG_HIP (hipDeviceSynchronize ()); // an earlier batch may still use what is about to be freed
 				ws.busy = false;
 			}
@@ -821,6 +853,19 @@ int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, 
 				OZG_HIP (hipMalloc ((void **)&ws.lz_probs, (size_t)t * OTZ_LZMA_PROB_BYTES));
 				ws.lz_threads = t;
 			}
+			if (want_br && br_threads > ws.br_threads) {
+				(void)hipFree (ws.br_arena);
+				ws.br_arena = nullptr;
+				ws.br_threads = 0;
+				const u32 t = br_threads < 256u ? 256u : 1024u;
+				OZG_HIP (hipMalloc ((void **)&ws.br_arena, (size_t)t * OTZ_BR_ARENA));
+				ws.br_threads = t;
+			}
+			if (want_br && !ws.br_blob) {
+				const size_t bytes = (size_t) (otz_brotli_blob_end - otz_brotli_blob);
+				OZG_HIP (hipMalloc ((void **)&ws.br_blob, bytes));
+				OZG_HIP (hipMemcpy (ws.br_blob, otz_brotli_blob, bytes, hipMemcpyHostToDevice));
+			}
 			if (n > ws.zs_route_cap) {
 				(void)hipFree (ws.zs_route);
 				ws.zs_route = nullptr;
@@ -834,6 +879,7 @@ int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, 
 			}
 			OZG_HIP (hipMemsetAsync (ws.zs_cursor, 0, 4, s));
 			OZG_HIP (hipMemsetAsync (ws.lz_cursor, 0, 4, s));
+			OZG_HIP (hipMemsetAsync (ws.br_cursor, 0, 4, s));
 			OZG_HIP (hipMemsetAsync (ws.zs_route, 0, n, s));
 			if (want_zs) {
 				if (g_prof) {
@@ -848,6 +894,11 @@ int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, 
 			if (want_lz) {
 				hipLaunchKernelGGL (otz_lzma_kernel, dim3 (lz_threads / 64u), dim3 (64), 0, s, (const u8 *)d_src, (u8 *)d_dst, d_entries, d_results, n,
 					(u64)src_len, (u64)dst_len, g_limits, ws.lz_probs, ws.lz_cursor, ws.zs_route);
+				OZG_HIP (hipGetLastError ());
+			}
+			if (want_br) {
+				hipLaunchKernelGGL (otz_brotli_kernel, dim3 (br_threads / 64u), dim3 (64), 0, s, (const u8 *)d_src, (u8 *)d_dst, d_entries, d_results, n,
+					(u64)src_len, (u64)dst_len, g_limits, ws.br_arena, (const u8 *)ws.br_blob, ws.br_cursor, ws.zs_route);
 				OZG_HIP (hipGetLastError ());
 			}
 			route = ws.zs_route;
@@ -867,7 +918,7 @@ int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, 
 
 // host-side view of a descriptor table: bounds, and which launches it needs
 int check_entries(const ozg_entry *entries, uint32_t n, uint64_t src_len, uint64_t dst_len, uint32_t *flags) {
-	uint32_t f = OZG_BATCH_NO_DEFLATE | OZG_BATCH_ONLY_DEFLATE | OZG_BATCH_NO_ZSTD | OZG_BATCH_NO_LZMA;
+	uint32_t f = OZG_BATCH_NO_DEFLATE | OZG_BATCH_ONLY_DEFLATE | OZG_BATCH_NO_ZSTD | OZG_BATCH_NO_LZMA | OZG_BATCH_NO_BROTLI;
 	for (uint32_t i = 0; i < n; i++) {
 		const ozg_entry &e = entries[i];
 		if (e.src_off > src_len || e.comp_size > src_len - e.src_off || (e.dst_off & 15u) || e.dst_off > dst_len ||
@@ -881,6 +932,9 @@ int check_entries(const ozg_entry *entries, uint32_t n, uint64_t src_len, uint64
 		}
 		if (e.method == OZG_METHOD_LZMA) {
 			f &= ~OZG_BATCH_NO_LZMA;
+		}
+		if (e.method == OZG_METHOD_BROTLI) {
+			f &= ~OZG_BATCH_NO_BROTLI;
 		}
 	}
 	*flags = f;

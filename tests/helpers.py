@@ -58,6 +58,7 @@ def layout(items):
 
 
 _emu = None
+_emu_blob = None
 
 
 def emu_lib():
@@ -81,6 +82,9 @@ def emu_lib():
         L.emu_lds_bytes_inflate.restype = C.c_uint32
         L.emu_lds_bytes_copy.restype = C.c_uint32
         L.emu_lds_bytes_apply.restype = C.c_uint32
+        global _emu_blob  # the RFC 7932 constant data the Brotli decoder reads (the library links it in)
+        _emu_blob = C.create_string_buffer(open(os.path.join(ROOT, "otezip_amd", "data", "brotli_rfc7932.bin"), "rb").read())
+        L.emu_set_brotli_blob(_emu_blob)
         _emu = L
     return _emu
 

@@ -8,6 +8,7 @@
 #include "otz_lz_apply.h"
 #include "otz_zstd.h"
 #include "otz_lzma.h"
+#include "otz_brotli.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -31,6 +32,10 @@ void otz_emu_yield() {
 	swapcontext (&w.fib[me], &w.fib[nx]);
 }
 #endif
+
+// the RFC 7932 constant data (otezip_amd/data/brotli_rfc7932.bin), set by the test before method-97 streams are decoded
+static const u8 *g_brotli_blob = nullptr;
+extern "C" void emu_set_brotli_blob(const void *p) { g_brotli_blob = (const u8 *)p; }
 
 namespace {
 
@@ -72,6 +77,12 @@ void *thread_main(void *p) {
 		const ozg_entry &e = *a->e;
 		if (otz_tid () == 0 && !otz_zipbomb (e, a->lim) && otz_lzma_is_candidate (a->src + e.src_off, e.comp_size)) {
 			otz_lzma_run (a->src + e.src_off, e.comp_size, a->dst + e.dst_off, e.uncomp_size, (u16 *)a->zs_lit, a->r, a->zs_route);
+		}
+	} else if (a->phase == 8) {
+		// what otz_brotli_kernel does for one entry (one work-item)
+		const ozg_entry &e = *a->e;
+		if (otz_tid () == 0 && !otz_zipbomb (e, a->lim) && otz_brotli_is_candidate (a->src + e.src_off, e.comp_size)) {
+			otz_brotli_run (a->src + e.src_off, e.comp_size, a->dst + e.dst_off, e.uncomp_size, a->zs_lit, g_brotli_blob, a->r, a->zs_route);
 		}
 	} else if (a->phase == 5) {
 		// what otz_zstd_crc_kernel does
@@ -275,6 +286,23 @@ extern "C" int emu_decode_batch_mode(const void *src, uint64_t src_len, void *ds
 			a.zs_lit = probs.data ();
 			a.zs_route = &route;
 			a.phase = 6;
+			run_block (64, a, 64);
+			a.phase = 0;
+			if (route != OTZ_ZS_ROUTE_DONE) {
+				run_block (OTZ_CNT, a, lds_bytes);
+			} else if (results[i].status == OZG_ST_OK) {
+				a.phase = 5;
+				run_block (OTZ_CNT, a, lds_bytes);
+			}
+			continue;
+		}
+		if (entries[i].method == OZG_METHOD_BROTLI && g_brotli_blob) {
+			// product order: Brotli kernel, copy kernel ("BROT" container) unless it decoded the entry, CRC pass
+			std::vector<u8> arena (OTZ_BR_ARENA, 0xA5);
+			u8 route = 0;
+			a.zs_lit = arena.data ();
+			a.zs_route = &route;
+			a.phase = 8;
 			run_block (64, a, 64);
 			a.phase = 0;
 			if (route != OTZ_ZS_ROUTE_DONE) {

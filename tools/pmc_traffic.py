@@ -28,11 +28,11 @@ def main():
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import kernel_build_id
     fetch_dir, write_dir, out = sys.argv[1], sys.argv[2], sys.argv[3]
-    kernels = sys.argv[4].split("+") if len(sys.argv) > 4 else ["otz_index_kernel", "otz_apply_kernel"]
+    kernels = sys.argv[4].split("+") if len(sys.argv) > 4 else ["otz_index_kernel", "otz_apply_kernel", "otz_out_crc_kernel"]
     f = w = 0.0
     per = {}
     nf = nw = 0
-    for kernel in kernels:  # the DEFLATE path is a pair of launches: their traffic adds up
+    for kernel in kernels:  # the DEFLATE path is three launches (index, apply, CRC pass): their traffic adds up
         fk, nf = mean_counter(fetch_dir + "/*/*counter_collection.csv", kernel, "FETCH_SIZE")
         wk, nw = mean_counter(write_dir + "/*/*counter_collection.csv", kernel, "WRITE_SIZE")
         per[kernel] = {"FETCH_SIZE_KiB_raw": fk, "WRITE_SIZE_KiB": wk, "traffic_bytes": (2 * fk + wk) * 1024}
