@@ -13,7 +13,8 @@
 // batch has one stream per entry.  So each work-item runs a straightforward decoder for its own entry:
 // 64 independent streams per wavefront.  Prefix codes are kept in canonical form (symbols sorted by code
 // length, counts per length) and decoded bit by bit -- compact (a meta-block may carry 3 x 256 codes) and
-// simple; the tables of a meta-block live in OTZ_BR_ARENA bytes of global scratch per work-item, the
+// simple; the tables of a meta-block live in global scratch (48 KB per work-item, 832 KB in a second pass for the
+// rare meta-block that needs it), the
 // entry's own output is the window.  The RFC's constant data (static dictionary, transforms, context
 // lookup) comes from otezip_amd/data/brotli_rfc7932.bin, uploaded once per device.
 // Large-window Brotli (WBITS > 24) is not RFC 7932 and is rejected.
@@ -101,15 +102,20 @@ struct otz_br_code {
 };
 
 OTZ_DEV u32 otz_br_symbol(otz_br_bits &b, const otz_br_code &c) {
-	if (c.cnt[0]) {
+	// the sixteen counts in two 16-byte loads: one trip to memory, then registers (the tables live in global
+	// memory, and a work-item has nothing else to do while it waits)
+	const otz_u4 lo = otz_ld16_aligned (c.cnt), hi = otz_ld16_aligned (c.cnt + 8);
+	const u32 w[8] = { lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w };
+	if (w[0] & 0xFFFFu) {
 		return c.sym[0];
 	}
 	u32 bits = otz_br_peek (b, 15);
 	u32 code = 0, first = 0, index = 0;
+#pragma unroll
 	for (u32 len = 1; len <= 15u; len++) {
 		code |= bits & 1u;
 		bits >>= 1;
-		const u32 count = c.cnt[len];
+		const u32 count = (w[len >> 1] >> (16u * (len & 1u))) & 0xFFFFu;
 		if (code < first + count) {
 			otz_br_drop (b, len);
 			return c.sym[index + (code - first)];
@@ -228,7 +234,8 @@ OTZ_DEV int otz_br_read_code(otz_br_bits &b, u32 alphabet, u8 *lens, otz_br_code
 	if (!(num == 1u || space == 0)) {
 		return OZG_ST_DATA;
 	}
-	u16 cl_cnt[16], cl_sym[18];
+	__attribute__ ((aligned (16))) u16 cl_cnt[16];
+	u16 cl_sym[18];
 	otz_br_code cc = { cl_cnt, cl_sym };
 	if (!otz_br_canon (cl, 18, cc)) {
 		return OZG_ST_DATA;
@@ -306,24 +313,32 @@ OTZ_DEV u32 otz_br_block_count(otz_br_bits &b, const otz_br_code &c) {
 
 // ------------------------------------------------------------------ scratch arena (one meta-block's tables)
 
+// Worst case of a meta-block: 256 literal codes, 256 insert-and-copy codes, 256 distance codes, the context
+// maps: about 800 KB.  Streams that ask for that much are rare (few block types, few trees is the rule), so the
+// batch is decoded in two passes: many work-items with OTZ_BR_ARENA_SMALL each, then the entries that ran
+// out of room again with OTZ_BR_ARENA each (otz_brotli_kernel, route value OTZ_BR_ROUTE_AGAIN).
 #define OTZ_BR_ARENA (832u * 1024u)
+#ifndef OTZ_BR_ARENA_SMALL
+#define OTZ_BR_ARENA_SMALL (48u * 1024u)
+#endif
+#define OTZ_BR_ROUTE_AGAIN 3u
 
 struct otz_br_arena {
-	u8 *base;
-	u32 used;
+	u8 *base; // 16-byte aligned
+	u32 used, cap;
 };
 OTZ_DEV u8 *otz_br_alloc(otz_br_arena &a, u32 bytes) {
-	const u32 at = (a.used + 3u) & ~3u;
-	if (at + bytes > OTZ_BR_ARENA) {
+	const u32 at = (a.used + 15u) & ~15u;
+	if (at + bytes > a.cap) {
 		return nullptr;
 	}
 	a.used = at + bytes;
 	return a.base + at;
 }
 OTZ_DEV bool otz_br_new_code(otz_br_arena &a, u32 alphabet, otz_br_code &c) {
-	c.cnt = reinterpret_cast<u16 *> (otz_br_alloc (a, 32u));
-	c.sym = reinterpret_cast<u16 *> (otz_br_alloc (a, 2u * alphabet));
-	return c.cnt != nullptr && c.sym != nullptr;
+	c.cnt = reinterpret_cast<u16 *> (otz_br_alloc (a, 32u + 2u * alphabet));
+	c.sym = c.cnt + 16;
+	return c.cnt != nullptr;
 }
 
 // section 7.3: a context map of `size` entries; *ntrees out.  Returns 0 or a status.
@@ -515,9 +530,10 @@ OTZ_DEV u32 otz_br_word(const otz_br_data &D, u32 len, u32 word_idx, u32 tr, u8 
 
 // ------------------------------------------------------------------ the stream
 
-// One Brotli stream, one work-item.  arena: OTZ_BR_ARENA bytes of scratch.  *produced = bytes written.
-// OZG_ST_OK, OZG_ST_DATA (not a valid stream), OZG_ST_SIZE (more than cap bytes), OZG_ST_INTERNAL (arena).
-OTZ_DEV int otz_brotli_stream(const u8 *in, u32 n_in, u8 *out, u32 cap, u8 *arena_base, const otz_br_data &D, u32 *produced) {
+// One Brotli stream, one work-item.  arena: arena_bytes of scratch (16-byte aligned).  *produced = bytes written.
+// OZG_ST_OK, OZG_ST_DATA (not a valid stream), OZG_ST_SIZE (more than cap bytes), OZG_ST_INTERNAL (a meta-block's
+// tables do not fit the arena).
+OTZ_DEV int otz_brotli_stream(const u8 *in, u32 n_in, u8 *out, u32 cap, u8 *arena_base, u32 arena_bytes, const otz_br_data &D, u32 *produced) {
 	otz_br_bits b = { in, n_in, 0, 0, 0 };
 	u32 pos = 0;
 	*produced = 0;
@@ -615,7 +631,7 @@ OTZ_DEV int otz_brotli_stream(const u8 *in, u32 n_in, u8 *out, u32 cap, u8 *aren
 			return OZG_ST_SIZE;
 		}
 		// ---- the rest of the header: block types, distance parameters, context maps, prefix codes
-		otz_br_arena A = { arena_base, 0 };
+		otz_br_arena A = { arena_base, 0, arena_bytes };
 		u8 *lens = otz_br_alloc (A, 1024u); // code lengths of the code being read (the largest alphabet has 704 symbols)
 		otz_br_cat cat[3];
 		for (u32 k = 0; k < 3u; k++) {
@@ -646,7 +662,7 @@ OTZ_DEV int otz_brotli_stream(const u8 *in, u32 n_in, u8 *out, u32 cap, u8 *aren
 		}
 		const u32 alpha_d = 16u + ndirect + (48u << npostfix);
 		// the codes of one kind are laid out at a fixed stride, so a tree is found by its number
-		const u32 stride_l = 32u + 2u * 256u, stride_i = 32u + 2u * 704u, stride_d = 32u + 2u * ((alpha_d + 1u) & ~1u);
+		const u32 stride_l = 32u + 2u * 256u, stride_i = 32u + 2u * 704u, stride_d = 32u + 2u * ((alpha_d + 7u) & ~7u); // (multiples of 16)
 		u8 *codes_l = otz_br_alloc (A, ntrees_l * stride_l);
 		u8 *codes_i = otz_br_alloc (A, cat[1].ntypes * stride_i);
 		u8 *codes_d = otz_br_alloc (A, ntrees_d * stride_d);
@@ -806,17 +822,20 @@ OTZ_DEV bool otz_brotli_is_candidate(const u8 *in, u32 n_in) {
 	return n_in >= 1u && !(n_in >= 4u && in[0] == 'B' && in[1] == 'R' && in[2] == 'O' && in[3] == 'T');
 }
 
-// One method-97 entry (one work-item).
-OTZ_DEV void otz_brotli_run(const u8 *in, u32 n_in, u8 *out, u32 cap, u8 *arena, const u8 *blob, ozg_result *res, u8 *route) {
+// One method-97 entry (one work-item).  With a small arena, an entry whose tables do not fit is marked
+// OTZ_BR_ROUTE_AGAIN for the second pass.
+OTZ_DEV void otz_brotli_run(const u8 *in, u32 n_in, u8 *out, u32 cap, u8 *arena, u32 arena_bytes, const u8 *blob, ozg_result *res, u8 *route) {
 	const otz_br_data D = otz_br_open (blob);
 	u32 total = 0;
-	const int st = otz_brotli_stream (in, n_in, out, cap, arena, D, &total);
+	const int st = otz_brotli_stream (in, n_in, out, cap, arena, arena_bytes, D, &total);
 	if (st == OZG_ST_OK && total == cap) {
 		res->status = OZG_ST_OK;
 		res->total_out = total;
 		res->crc32 = 0;
 		res->flags = 0;
 		*route = 2u; // OTZ_ZS_ROUTE_DONE: the CRC pass follows
+	} else if (st == OZG_ST_INTERNAL && arena_bytes < OTZ_BR_ARENA) {
+		*route = OTZ_BR_ROUTE_AGAIN;
 	} else {
 		*route = 1u; // OTZ_ZS_ROUTE_PRIVATE: the reference's container decoder has the last word
 	}

@@ -53,6 +53,7 @@ static_assert (sizeof (otz_ix_head) == 32 && sizeof (otz_ix_block) == 32 && size
 #define OTZ_K2_WPE (2 * OTZ_K2_WGS)
 #endif
 static_assert (sizeof (otz_apply_lds) <= 160 * 1024 / OTZ_K2_WGS, "apply workgroups per CU");
+#define OTZ_BR_BIG_THREADS 512u // work-items of the Brotli kernel's second pass (832 KB of scratch each)
 #ifndef OTZ_ZS_WPE
 #define OTZ_ZS_WPE 4 // the Zstandard kernel's LDS (10.6 KB) admits 15 wavefronts per CU: registers must not halve that
 #endif
@@ -228,22 +229,27 @@ otz_lzma_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *re
 }
 
 // Brotli streams under method 97 (otz_brotli.h): one work-item per stream, a persistent grid; every work-item
-// owns OTZ_BR_ARENA bytes of scratch for the tables of the meta-block it is in.  blob: brotli_rfc7932.bin.
+// owns arena_bytes of scratch for the tables of the meta-block it is in.  Launched twice: many work-items with
+// small arenas, then (again != 0) few with large ones for the entries the first pass marked.  blob: brotli_rfc7932.bin.
 extern "C" __global__ void __launch_bounds__ (64)
 otz_brotli_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *results, u32 n, u64 src_len, u64 dst_len, ozg_limits lim,
-	u8 *arena, const u8 *blob, u32 *cursor, u8 *route) {
-	u8 *mine = arena + (size_t) (blockIdx.x * 64u + threadIdx.x) * OTZ_BR_ARENA;
+	u8 *arena, u32 arena_bytes, const u8 *blob, u32 *cursor, u8 *route, u32 again) {
+	u8 *mine = arena + (size_t) (blockIdx.x * 64u + threadIdx.x) * arena_bytes;
 	for (;;) {
 		const u32 i = atomicAdd (cursor, 1u);
 		if (i >= n) {
 			break;
 		}
 		const ozg_entry e = entries[i];
-		if (e.method != OZG_METHOD_BROTLI || !otz_entry_in_bounds (e, src_len, dst_len) || otz_zipbomb (e, lim) ||
+		if (again) {
+			if (route[i] != OTZ_BR_ROUTE_AGAIN) {
+				continue;
+			}
+		} else if (e.method != OZG_METHOD_BROTLI || !otz_entry_in_bounds (e, src_len, dst_len) || otz_zipbomb (e, lim) ||
 			!otz_brotli_is_candidate (src + e.src_off, e.comp_size)) {
 			continue; // the copy kernel's (route stays 0)
 		}
-		otz_brotli_run (src + e.src_off, e.comp_size, dst + e.dst_off, e.uncomp_size, mine, blob, &results[i], &route[i]);
+		otz_brotli_run (src + e.src_off, e.comp_size, dst + e.dst_off, e.uncomp_size, mine, arena_bytes, blob, &results[i], &route[i]);
 	}
 }
 
@@ -559,8 +565,9 @@ struct workspace {
 	u8 *lz_probs = nullptr;
 	u32 lz_threads = 0;
 	u32 *lz_cursor = nullptr;
-	u8 *br_arena = nullptr; // Brotli: OTZ_BR_ARENA bytes per work-item
+	u8 *br_arena = nullptr; // Brotli: OTZ_BR_ARENA_SMALL bytes per work-item of the first pass,
 	u32 br_threads = 0;
+	u8 *br_big = nullptr;   // OTZ_BR_ARENA for each of the OTZ_BR_BIG_THREADS of the second
 	u32 *br_cursor = nullptr;
 	u8 *br_blob = nullptr;  // the RFC's constant data on this device
 	// encode side: token scratch of the persistent grid, its buffer counter
@@ -715,21 +722,13 @@ int ws_reserve(workspace &ws, uint64_t src_len, uint64_t dst_len, uint32_t n) {
 }
 
 void ws_free(workspace &ws) {
-	(void)hipFree (ws.arena);
-	(void)hipFree (ws.regions);
-	(void)hipFree (ws.heads);
-	(void)hipFree (ws.cursor);
-	(void)hipFree (ws.ovf);
-	(void)hipFree (ws.enc_tok);
-	(void)hipFree (ws.enc_cursor);
-	(void)hipFree (ws.zs_lit);
-	(void)hipFree (ws.zs_cursor);
-	(void)hipFree (ws.zs_route);
-	(void)hipFree (ws.lz_probs);
-	(void)hipFree (ws.lz_cursor);
-	(void)hipFree (ws.br_arena);
-	(void)hipFree (ws.br_cursor);
-	(void)hipFree (ws.br_blob);
+	void *const owned[] = { ws.arena, ws.regions, ws.heads, ws.cursor, ws.ovf, ws.enc_tok, ws.enc_cursor, ws.zs_lit, ws.zs_cursor, ws.zs_route, ws.lz_probs, ws.lz_cursor, ws.br_arena, ws.br_big, ws.br_cursor, ws.br_blob };
+	for (size_t k = 0; k < sizeof (owned) / sizeof (owned[0]); k++) {
+		const hipError_t e = hipFree (owned[k]);
+		if (e != hipSuccess && getenv ("OTEZIP_TRACE")) {
+			fprintf (stderr, "[otezip-amd] hipFree of workspace block %d (%p): %s\n", (int)k, owned[k], hipGetErrorString (e));
+		}
+	}
 	if (ws.enc_done) {
 		(void)hipEventDestroy (ws.enc_done);
 	}
@@ -752,6 +751,12 @@ hipEvent_t ws_done_event(dev_ctx &C) { return C.ws.done; }
 int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, uint64_t dst_len, const ozg_entry *d_entries,
 	ozg_result *d_results, uint32_t n, hipStream_t s, uint32_t batch_flags, u64 *d_end_bits = nullptr) {
 	int rc;
+	{ // an error some earlier, unchecked call of this thread left behind (here or in another library) is not this batch's
+		const hipError_t stale = hipGetLastError ();
+		if (stale != hipSuccess && getenv ("OTEZIP_TRACE")) {
+			fprintf (stderr, "[otezip-amd] stale HIP error before a decode batch: %s\n", hipGetErrorString (stale));
+		}
+	}
 	if (!(batch_flags & OZG_BATCH_NO_DEFLATE)) {
 		workspace &ws = C.ws;
 		if ((rc = ws_reserve (ws, src_len, dst_len, n)) != OZG_OK) {
@@ -824,7 +829,7 @@ int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, 
 			workspace &ws = C.ws;
 			const u32 grid = n < C.zs_grid ? n : C.zs_grid;
 			const u32 lz_threads = ((n < 32768u ? n : 32768u) + 63u) & ~63u;
-			const u32 br_threads = ((n < 1024u ? n : 1024u) + 63u) & ~63u;
+			const u32 br_threads = ((n < 16384u ? n : 16384u) + 63u) & ~63u;
 			if (!ws.done) {
 				OZG_HIP (hipEventCreateWithFlags (&ws.done, hipEventDisableTiming));
 			}
@@ -857,9 +862,12 @@ int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, 
 				(void)hipFree (ws.br_arena);
 				ws.br_arena = nullptr;
 				ws.br_threads = 0;
-				const u32 t = br_threads < 256u ? 256u : 1024u;
-				OZG_HIP (hipMalloc ((void **)&ws.br_arena, (size_t)t * OTZ_BR_ARENA));
+				const u32 t = br_threads < 1024u ? 1024u : (br_threads + (br_threads >> 1) < 16384u ? (br_threads + (br_threads >> 1) + 63u) & ~63u : 16384u);
+				OZG_HIP (hipMalloc ((void **)&ws.br_arena, (size_t)t * OTZ_BR_ARENA_SMALL));
 				ws.br_threads = t;
+			}
+			if (want_br && !ws.br_big) {
+				OZG_HIP (hipMalloc ((void **)&ws.br_big, (size_t)OTZ_BR_BIG_THREADS * OTZ_BR_ARENA));
 			}
 			if (want_br && !ws.br_blob) {
 				const size_t bytes = (size_t) (otz_brotli_blob_end - otz_brotli_blob);
@@ -879,7 +887,7 @@ int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, 
 			}
 			OZG_HIP (hipMemsetAsync (ws.zs_cursor, 0, 4, s));
 			OZG_HIP (hipMemsetAsync (ws.lz_cursor, 0, 4, s));
-			OZG_HIP (hipMemsetAsync (ws.br_cursor, 0, 4, s));
+			OZG_HIP (hipMemsetAsync (ws.br_cursor, 0, 8, s)); // (one counter per pass)
 			OZG_HIP (hipMemsetAsync (ws.zs_route, 0, n, s));
 			if (want_zs) {
 				if (g_prof) {
@@ -898,7 +906,10 @@ int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, 
 			}
 			if (want_br) {
 				hipLaunchKernelGGL (otz_brotli_kernel, dim3 (br_threads / 64u), dim3 (64), 0, s, (const u8 *)d_src, (u8 *)d_dst, d_entries, d_results, n,
-					(u64)src_len, (u64)dst_len, g_limits, ws.br_arena, (const u8 *)ws.br_blob, ws.br_cursor, ws.zs_route);
+					(u64)src_len, (u64)dst_len, g_limits, ws.br_arena, OTZ_BR_ARENA_SMALL, (const u8 *)ws.br_blob, ws.br_cursor, ws.zs_route, 0u);
+				OZG_HIP (hipGetLastError ());
+				hipLaunchKernelGGL (otz_brotli_kernel, dim3 (OTZ_BR_BIG_THREADS / 64u), dim3 (64), 0, s, (const u8 *)d_src, (u8 *)d_dst, d_entries, d_results, n,
+					(u64)src_len, (u64)dst_len, g_limits, ws.br_big, OTZ_BR_ARENA, (const u8 *)ws.br_blob, ws.br_cursor + 1, ws.zs_route, 1u);
 				OZG_HIP (hipGetLastError ());
 			}
 			route = ws.zs_route;

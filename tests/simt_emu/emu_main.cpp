@@ -82,7 +82,7 @@ void *thread_main(void *p) {
 		// what otz_brotli_kernel does for one entry (one work-item)
 		const ozg_entry &e = *a->e;
 		if (otz_tid () == 0 && !otz_zipbomb (e, a->lim) && otz_brotli_is_candidate (a->src + e.src_off, e.comp_size)) {
-			otz_brotli_run (a->src + e.src_off, e.comp_size, a->dst + e.dst_off, e.uncomp_size, a->zs_lit, g_brotli_blob, a->r, a->zs_route);
+			otz_brotli_run (a->src + e.src_off, e.comp_size, a->dst + e.dst_off, e.uncomp_size, a->zs_lit, a->region_bytes, g_brotli_blob, a->r, a->zs_route);
 		}
 	} else if (a->phase == 5) {
 		// what otz_zstd_crc_kernel does
@@ -298,12 +298,18 @@ extern "C" int emu_decode_batch_mode(const void *src, uint64_t src_len, void *ds
 		}
 		if (entries[i].method == OZG_METHOD_BROTLI && g_brotli_blob) {
 			// product order: Brotli kernel, copy kernel ("BROT" container) unless it decoded the entry, CRC pass
-			std::vector<u8> arena (OTZ_BR_ARENA, 0xA5);
+			// (two passes: a small arena, then a large one for the entry that ran out of room)
+			std::vector<u8> arena (OTZ_BR_ARENA + 16, 0xA5);
 			u8 route = 0;
-			a.zs_lit = arena.data ();
+			a.zs_lit = (u8 *) (((uintptr_t)arena.data () + 15u) & ~(uintptr_t)15u);
 			a.zs_route = &route;
 			a.phase = 8;
+			a.region_bytes = OTZ_BR_ARENA_SMALL;
 			run_block (64, a, 64);
+			if (route == OTZ_BR_ROUTE_AGAIN) {
+				a.region_bytes = OTZ_BR_ARENA;
+				run_block (64, a, 64);
+			}
 			a.phase = 0;
 			if (route != OTZ_ZS_ROUTE_DONE) {
 				run_block (OTZ_CNT, a, lds_bytes);

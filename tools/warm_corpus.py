@@ -25,6 +25,11 @@ def main():
         zstd_corpus.build_zstd_real(n, 65536)
     except Exception as ex:
         print("real zstd corpus unavailable: %r" % (ex,))
+    try:
+        zstd_corpus.build_brotli_real(n, 65536)
+        zstd_corpus.build_lzma_real(n, 65536)
+    except Exception as ex:
+        print("real Brotli / LZMA corpus unavailable: %r" % (ex,))
     print("corpora cached")
 
 
