@@ -34,11 +34,13 @@
 #include "otz_index.h"
 
 #ifndef OTZ_K1_S
-#define OTZ_K1_S 512u     // segment bits per lane per round
+#define OTZ_K1_S 512u     // segment bits per lane per round (256 was measured: see DESIGN.md section 7)
 #endif
 #ifndef OTZ_K1_WARM
 #define OTZ_K1_WARM 128u  // head start of walk A (bits)
 #endif
+#define OTZ_K1_SEGW (OTZ_K1_S / 32u)                    // words of a lane's segment: 16 or 8
+#define OTZ_K1_SEGSH (OTZ_K1_S == 512u ? 4u : 3u)       // log2 of that
 #define OTZ_K1_SLOT (OTZ_K1_WARM / 8u + OTZ_K1_S / 8u + 12u) // bytes a lane may touch: WARM/8 before its segment + S/8 + 12 behind
 // The round's input sits in LDS ONCE, as one window: [segment of lane 0 - WARM/8 bytes, segment of lane 63
 // + 12 bytes).  A lane's warm-up stretch is its left neighbour's tail and its look-ahead its right
@@ -46,14 +48,14 @@
 // trimmed tables the wavefront fits 8 KB of LDS, i.e. five wavefronts per SIMD instead of four).
 // Lanes read at the same offset of their 16-word segments: one padding word after every 16 makes the
 // lane stride 17 words, which keeps those reads on different banks.
-#define OTZ_K1_WIN_BYTES (OTZ_K1_WARM / 8u + 64u * (OTZ_K1_S / 8u) + 16u) // 16 + 4096 + 16
+#define OTZ_K1_WIN_BYTES (OTZ_K1_WARM / 8u + 64u * (OTZ_K1_S / 8u) + 16u) // 16 + 4096 (or 2048) + 16
 #define OTZ_K1_WIN_WORDS (OTZ_K1_WIN_BYTES / 4u)
-#define OTZ_K1_WIN_PADDED (OTZ_K1_WIN_WORDS + OTZ_K1_WIN_WORDS / 16u + 2u)
+#define OTZ_K1_WIN_PADDED (OTZ_K1_WIN_WORDS + OTZ_K1_WIN_WORDS / OTZ_K1_SEGW + 2u)
 #define OTZ_K1_NCAP (OTZ_K1_ROWS * OTZ_IX_G) // tokens a walk may take per round
 #define OTZ_K1_HDR_WORDS 264u // staged bytes for a block header: 17 + 57 + 318 x 14 bits < 1056 bytes
 
 static_assert (OTZ_K1_S % 8u == 0 && OTZ_K1_WARM % 8u == 0, "byte-granular slots");
-static_assert (OTZ_K1_S == 512u && OTZ_K1_WARM == 128u, "a lane's segment is 16 words, its slot starts 4 words before it");
+static_assert ((OTZ_K1_S == 512u || OTZ_K1_S == 256u) && OTZ_K1_WARM == 128u, "a lane's segment is 16 or 8 words, its slot starts 4 words before it");
 static_assert (OTZ_K1_SLOT >= OTZ_K1_WARM / 8u + OTZ_K1_S / 8u + 9u, "a token starting on the segment's last bit must fit");
 static_assert ((OTZ_IX_G & (OTZ_IX_G - 1u)) == 0, "power of two");
 
@@ -489,13 +491,13 @@ OTZ_DEV otz_k1_tok otz_k1_decode_bits(const otz_k1_lds &L, u32 lo, u32 hi) {
 }
 
 // The three window words from the one that holds slot-relative bit u of the lane whose slot starts at
-// window word `slot` (= 16 x lane): dword-aligned reads and a funnel shift (a byte-unaligned 8-byte LDS
+// window word `slot` (= OTZ_K1_SEGW x lane): dword-aligned reads and a funnel shift (a byte-unaligned 8-byte LDS
 // read costs 5x the LDS time); word i of the window lives at win[i + i / 16].
 OTZ_DEV void otz_k1_words(const otz_k1_lds &L, u32 slot, u32 u, u32 &w0, u32 &w1, u32 &w2) {
 	const u32 i0 = slot + otz_opaque (u >> 5), i1 = i0 + 1u, i2 = i0 + 2u;
-	w0 = L.win[i0 + (i0 >> 4)];
-	w1 = L.win[i1 + (i1 >> 4)];
-	w2 = L.win[i2 + (i2 >> 4)];
+	w0 = L.win[i0 + (i0 >> OTZ_K1_SEGSH)];
+	w1 = L.win[i1 + (i1 >> OTZ_K1_SEGSH)];
+	w2 = L.win[i2 + (i2 >> OTZ_K1_SEGSH)];
 }
 OTZ_DEV otz_k1_tok otz_k1_decode(const otz_k1_lds &L, u32 slot, u32 u) {
 	u32 w0, w1, w2;
@@ -873,14 +875,14 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 		// ---- rounds
 		while (!block_done && status == 0) {
 			const u32 rb = (u32) (abs_bit >> 3), phi = (u32) (abs_bit & 7u);
-			const int64_t slot0 = (int64_t)rb + 64 * (int64_t)lane - (int64_t) (OTZ_K1_WARM / 8u); // entry byte of the slot's byte 0
-			const u32 slot = 16u * lane; // window word of this lane's slot byte 0
+			const int64_t slot0 = (int64_t)rb + (int64_t) (OTZ_K1_S / 8u) * (int64_t)lane - (int64_t) (OTZ_K1_WARM / 8u); // entry byte of the slot's byte 0
+			const u32 slot = OTZ_K1_SEGW * lane; // window word of this lane's slot byte 0
 			otz_wave_sync (); // prologue scratch / previous round's window are dead
 			{
 				const int64_t win0 = (int64_t)rb - (int64_t) (OTZ_K1_WARM / 8u); // entry byte of window byte 0
 				for (u32 c = lane; c < OTZ_K1_WIN_BYTES / 16u; c += 64u) { // coalesced 16-byte loads, 4 words each
 					const otz_u4 v = otz_k1_ld16 (in, n_in, win0 + 16 * (int64_t)c);
-					u32 *d = &L.win[4u * c + (c >> 2)]; // (4c .. 4c+3 lie inside one group of 16: one padding offset)
+					u32 *d = &L.win[4u * c + (c >> (OTZ_K1_SEGSH - 2u))]; // (4c .. 4c+3 lie inside one segment-sized group: one padding offset)
 					d[0] = v.x;
 					d[1] = v.y;
 					d[2] = v.z;
@@ -1029,7 +1031,7 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 			// where the stream goes on (lane F's exit), and how the block ends
 			const u32 fexit = otz_readlane (exit_cur, F);
 			const u32 ftstart = otz_readlane (onA ? A.tstart : tstartB, F);
-			const u64 fslot_bit = (u64) (8 * ((int64_t)rb + 64 * (int64_t)F - (int64_t) (OTZ_K1_WARM / 8u)));
+			const u64 fslot_bit = (u64) (8 * ((int64_t)rb + (int64_t) (OTZ_K1_S / 8u) * (int64_t)F - (int64_t) (OTZ_K1_WARM / 8u)));
 			abs_bit = fslot_bit + OTZ_X_POS (fexit);
 			if (fkind == OTZ_X_EOB) {
 				block_done = true;
