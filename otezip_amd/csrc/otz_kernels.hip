@@ -586,6 +586,7 @@ struct ozg_job {
 	bool busy = false;
 	hipStream_t stream = nullptr;
 	hipEvent_t done = nullptr;
+	hipEvent_t up = nullptr; // decode jobs: the input is on the device
 	staging st;
 	void *h_ent = nullptr; // pinned copy of the descriptor table (+ 64 bytes: the packed total comes back there)
 	size_t h_ent_cap = 0;
@@ -607,6 +608,10 @@ struct dev_ctx {
 	staging stage; // synchronous host entry points
 	workspace ws;
 	ozg_job slots[N_SLOTS];
+	// The copies of the decode jobs of a device go first come, first served: two uploads (or two downloads) of
+	// jobs in flight would otherwise share the link, and the job submitted first -- the one its caller waits
+	// for -- would finish as late as the second.
+	hipEvent_t h2d_tail = nullptr, d2h_tail = nullptr;
 } g_dev[MAX_DEV];
 
 int fail_hip(const char *what, hipError_t e) {
@@ -1081,8 +1086,12 @@ void ozg_shutdown(void) {
 			if (j.mid) {
 				(void)hipEventDestroy (j.mid);
 			}
+			if (j.up) {
+				(void)hipEventDestroy (j.up);
+			}
 			j = ozg_job ();
 		}
+		C.h2d_tail = C.d2h_tail = nullptr; // (they were events of the slots)
 		C.ready = false;
 	}
 	g_default = -1;
@@ -1234,15 +1243,27 @@ int ozg_decode_submit(const void *h_src, uint64_t src_len, void *h_dst, uint64_t
 	}
 	memcpy (J->h_ent, entries, ent_bytes); // (the caller's table may be gone before the copy runs)
 	hipStream_t s = J->stream;
+	if (!J->up) {
+		OZG_HIP (hipEventCreateWithFlags (&J->up, hipEventDisableTiming));
+	}
+	if (C->h2d_tail) {
+		OZG_HIP (hipStreamWaitEvent (s, C->h2d_tail, 0));
+	}
 	OZG_HIP (hipMemcpyAsync (J->st.d_src, h_src, src_len, hipMemcpyHostToDevice, s));
 	OZG_HIP (hipMemcpyAsync (J->st.d_ent, J->h_ent, ent_bytes, hipMemcpyHostToDevice, s));
+	OZG_HIP (hipEventRecord (J->up, s));
+	C->h2d_tail = J->up;
 	rc = launch_decode (*C, J->st.d_src, src_len, J->st.d_dst, dst_len, (const ozg_entry *)J->st.d_ent, (ozg_result *)J->st.d_res, n, s, flags);
 	if (rc != OZG_OK) {
 		return rc;
 	}
+	if (C->d2h_tail) {
+		OZG_HIP (hipStreamWaitEvent (s, C->d2h_tail, 0));
+	}
 	OZG_HIP (hipMemcpyAsync (h_dst, J->st.d_dst, dst_len, hipMemcpyDeviceToHost, s));
 	OZG_HIP (hipMemcpyAsync (h_results, J->st.d_res, (size_t)n * sizeof (ozg_result), hipMemcpyDeviceToHost, s));
 	OZG_HIP (hipEventRecord (J->done, s));
+	C->d2h_tail = J->done;
 	J->busy = true;
 	*job = J;
 	return OZG_OK;

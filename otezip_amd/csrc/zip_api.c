@@ -48,9 +48,10 @@
 #define WIN_MAX_OUT (96ull << 20)
 #define READ_THREADS_MAX 16
 static int g_read_threads = 4; /* a window's stretch of the file is read by this many pread()s in parallel (OTEZIP_READ_THREADS) */
-static int g_ahead_min = 1;    /* windows kept in preparation behind the current one, at least (OTEZIP_READ_AHEAD); measured on the
-                                * bench archive (tools/api_rates.sh): 8-16 threads or a depth of 2-4 are no faster than 4 / 1 --
-                                * the D2H copy of the outputs is what a warm pass waits for */
+static int g_ahead_min = 2;    /* windows kept in preparation behind the current one, at least (OTEZIP_READ_AHEAD).  A window's way to
+                                * its D2H copy -- read 0.6 ms, H2D 0.5, kernels 0.35 -- is longer than the copy itself (1.3 ms for
+                                * 67 MB): with one window ahead the copy engine idles 0.3 ms per window, with two (submitted in
+                                * order, copies first come first served) it does not (tools/api_rates.sh, tools/api_trace.sh) */
 #define AHEAD_MAX 8    /* windows prepared ahead of a sequential reader: one per device (OTEZIP_GPU_DEVICES), at most this many */
 #define FLIGHTS_MAX (AHEAD_MAX + 1) /* encode batches in flight while a flush writes: one per device + the one being written */
 /* Pending adds are flushed at this many source bytes / entries: the ZIP32 limits, so that in
@@ -116,6 +117,7 @@ struct ozh_zip {
 	zip_uint64_t grow;     /* size of the next read-ahead window */
 	uint32_t cd_ofs;       /* start of the central directory when the archive was opened */
 	int ndev, next_dev;
+	unsigned long sub_next, sub_done; /* windows are submitted in the order they were begun (tickets: g_sub_mu) */
 	/* deferred zip_file_add: sources, in index order */
 	struct pchunk *pch;
 	size_t npch, pchcap;
@@ -853,13 +855,49 @@ struct win_fill {
 	int one_span;
 	int dev;
 	ozg_entry *ents;
+	unsigned long ticket;
+	int ticket_held;
 };
+
+/* The copies of a device's jobs run first come, first served (otz_kernels.hip), so the order of submission is
+ * the order of completion: windows filled by helper threads must not overtake each other on the way to the
+ * GPU, or the one the reader waits for queues behind the one after it.  A window takes a ticket when it is
+ * begun, waits for its turn right before the submit and gives the turn on whatever happens. */
+static pthread_mutex_t g_sub_mu = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t g_sub_cv = PTHREAD_COND_INITIALIZER;
+
+static void ticket_take(struct ozh_zip *z, struct win_fill *F) {
+	pthread_mutex_lock (&g_sub_mu);
+	F->ticket = z->sub_next++;
+	F->ticket_held = 1;
+	pthread_mutex_unlock (&g_sub_mu);
+}
+static void ticket_wait(struct ozh_zip *z, const struct win_fill *F) {
+	pthread_mutex_lock (&g_sub_mu);
+	while (F->ticket_held && z->sub_done != F->ticket) {
+		pthread_cond_wait (&g_sub_cv, &g_sub_mu);
+	}
+	pthread_mutex_unlock (&g_sub_mu);
+}
+static void ticket_release(struct ozh_zip *z, struct win_fill *F) {
+	if (!F->ticket_held) {
+		return;
+	}
+	pthread_mutex_lock (&g_sub_mu);
+	while (z->sub_done != F->ticket) { /* (left before its turn -- an early failure: the turn still passes in order) */
+		pthread_cond_wait (&g_sub_cv, &g_sub_mu);
+	}
+	z->sub_done = F->ticket + 1u;
+	F->ticket_held = 0;
+	pthread_cond_broadcast (&g_sub_cv);
+	pthread_mutex_unlock (&g_sub_mu);
+}
 
 /* Second half of window_begin: read the window's bytes, check the local headers (ref otezip.c:411-446),
  * submit the batch.  Runs on the caller's thread, or on a helper thread for a read-ahead window of a
  * read-only archive (then only pread() on the descriptor is used: the FILE's position belongs to the
  * caller).  Returns 0, -1, or 1: "the layout is not what the one-read path assumes, take the packed road". */
-static int window_fill(struct window *w) {
+static int window_fill_body(struct window *w) {
 	struct win_fill *F = w->fill;
 	zip_t *za = F->za;
 	const zip_uint64_t first = w->first, count = w->count;
@@ -932,10 +970,12 @@ static int window_fill(struct window *w) {
 		ozg_limits lim = { otezip_max_expansion_ratio, otezip_max_expansion_slack };
 		ozg_set_limits (&lim);
 		const uint64_t src_len = (one_span ? hi - lo : packed) + 16u, dst_len = F->out + 16u;
+		ticket_wait ((struct ozh_zip *)za, F);
 		int rc = ozg_use_device (F->dev);
 		if (rc == OZG_OK) {
 			rc = ozg_decode_submit (w->b.src, src_len, w->b.out, dst_len, F->ents, w->b.res, nb, &w->job);
 		}
+		ticket_release ((struct ozh_zip *)za, F);
 		if (rc == OZG_E_NOMEM) {
 			/* every staged-batch slot of the device is taken (other archives walk their windows too):
 			 * back-pressure, not an error.  A read-ahead window gives up quietly -- the reader starts
@@ -963,6 +1003,12 @@ static int window_fill(struct window *w) {
 	}
 	TRACE ("window [%llu): submitted %u entries", (unsigned long long)first, nb);
 	return 0;
+}
+
+static int window_fill(struct window *w) {
+	const int rc = window_fill_body (w);
+	ticket_release ((struct ozh_zip *)w->fill->za, w->fill);
+	return rc;
 }
 
 static void win_fill_free(struct window *w) {
@@ -1087,6 +1133,7 @@ static struct window *window_begin_ex(zip_t *za, zip_uint64_t first, zip_uint64_
 	F->one_span = one_span;
 	/* the devices take the windows in turn */
 	F->dev = g_dev0 + (z->next_dev++ % (g_ndev > 0 ? g_ndev : 1));
+	ticket_take (z, F);
 	if (ahead && one_span && za->mode == 0 && pthread_create (&w->th, NULL, window_fill_thread, w) == 0) {
 		w->th_live = 1; /* the caller's thread goes on consuming the current window meanwhile */
 		return w;

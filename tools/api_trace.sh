@@ -6,4 +6,4 @@ import sys; sys.path.insert(0,'.')
 from otezip_amd import corpus
 arc,_=corpus.build_archive(10000,65536); open('/tmp/big.zip','wb').write(arc)"
 OTEZIP_TRACE=1 OTEZIP_READ_THREADS=8 /tmp/zrt bench-extract /tmp/big.zip 0 3 2>&1 | grep -v "^[0-9]* [0-9a-f]* " | tail -120 > gpurun_out/api_trace.txt
-tail -64 gpurun_out/api_trace.txt | head -24
+tail -75 gpurun_out/api_trace.txt
