@@ -655,6 +655,40 @@ static int read_span(FILE *fp, uint8_t *dst, uint64_t off, uint64_t len) {
 	return ok ? 0 : -1;
 }
 
+/* memcpy of a large block by the reader's threads (a chunk of sources on its way into pinned memory) */
+struct copy_job {
+	uint8_t *dst;
+	const uint8_t *src;
+	size_t len;
+};
+static void *copy_run(void *p) {
+	const struct copy_job *j = (const struct copy_job *)p;
+	memcpy (j->dst, j->src, j->len);
+	return NULL;
+}
+static void copy_span(uint8_t *dst, const uint8_t *src, size_t len) {
+	const int nt = len >= ((size_t)4 << 20) ? g_read_threads : 1;
+	struct copy_job job[READ_THREADS_MAX];
+	pthread_t th[READ_THREADS_MAX];
+	int started[READ_THREADS_MAX];
+	const size_t piece = ((len + (size_t)nt - 1u) / (size_t)nt + 4095u) & ~(size_t)4095u;
+	for (int i = 0; i < nt; i++) {
+		const size_t o = piece * (size_t)i;
+		job[i].dst = dst + o;
+		job[i].src = src + o;
+		job[i].len = o >= len ? 0 : (len - o < piece ? len - o : piece);
+		started[i] = i > 0 && job[i].len && pthread_create (&th[i], NULL, copy_run, &job[i]) == 0;
+	}
+	copy_run (&job[0]);
+	for (int i = 1; i < nt; i++) {
+		if (started[i]) {
+			pthread_join (th[i], NULL);
+		} else if (job[i].len) {
+			copy_run (&job[i]);
+		}
+	}
+}
+
 static void put16(uint8_t *p, uint16_t v) { otezip_write_le16 (p, v); }
 static void put32(uint8_t *p, uint32_t v) { otezip_write_le32 (p, v); }
 
@@ -1381,9 +1415,45 @@ void zip_source_free(zip_source_t *src) {
  * input; local headers and payloads are then written in index order.  Methods 93/100/97
  * always end as STORE, exactly as in the reference, whose writers for them only add bytes
  * (SURVEY F9). */
+/* Chunk buffers of the standard size are kept for the next flush (of this or another archive) instead of going
+ * back to the allocator: a fresh 32 MiB block is page-faulted in while the caller's bytes are copied into it,
+ * and that, not the copy, was two thirds of the time of a run of zip_file_add calls (tools/api_add_trace.sh).
+ * At most CHUNK_POOL_MAX buffers (1 GiB) stay parked. */
+#define CHUNK_POOL_MAX 32
+static pthread_mutex_t g_chunk_mu = PTHREAD_MUTEX_INITIALIZER;
+static uint8_t *g_chunk_pool[CHUNK_POOL_MAX];
+static int g_chunk_n;
+
+static uint8_t *chunk_alloc(size_t cap) {
+	if (cap == PCHUNK_BYTES) {
+		uint8_t *p = NULL;
+		pthread_mutex_lock (&g_chunk_mu);
+		if (g_chunk_n > 0) {
+			p = g_chunk_pool[--g_chunk_n];
+		}
+		pthread_mutex_unlock (&g_chunk_mu);
+		if (p) {
+			return p;
+		}
+	}
+	return (uint8_t *)malloc (cap);
+}
+
+static void chunk_free(uint8_t *p, size_t cap) {
+	if (p && cap == PCHUNK_BYTES) {
+		pthread_mutex_lock (&g_chunk_mu);
+		if (g_chunk_n < CHUNK_POOL_MAX) {
+			g_chunk_pool[g_chunk_n++] = p;
+			p = NULL;
+		}
+		pthread_mutex_unlock (&g_chunk_mu);
+	}
+	free (p);
+}
+
 static void pending_drop(struct ozh_zip *z) {
 	for (size_t k = 0; k < z->npch; k++) {
-		free (z->pch[k].buf);
+		chunk_free (z->pch[k].buf, z->pch[k].cap);
 	}
 	z->npch = 0;
 	z->pn = 0;
@@ -1427,7 +1497,7 @@ static int enc_start(zip_t *za, size_t k, struct enc_flight *f) {
 		f->ee = NULL;
 		return -1;
 	}
-	memcpy (f->b.src, c->buf, c->used);
+	copy_span (f->b.src, c->buf, c->used);
 	/* the devices take the batches in turn (OTEZIP_GPU_DEVICES), like the reader's windows */
 	if (ozg_use_device (g_dev0 + (int) (k % (size_t) (g_ndev > 0 ? g_ndev : 1))) != OZG_OK ||
 		ozg_encode_submit_packed (f->b.src, c->used + 16, f->b.out, ocap + 16, f->ee, (ozg_enc_result *)f->b.res, (uint32_t)c->nitems, &f->job) != OZG_OK) {
@@ -1587,7 +1657,7 @@ static uint8_t *pending_reserve(struct ozh_zip *z, size_t len, uint64_t *off, in
 		c = &z->pch[z->npch];
 		memset (c, 0, sizeof (*c));
 		c->cap = exact || alen + 64 > PCHUNK_BYTES ? alen + 64 : PCHUNK_BYTES; /* (a replace is a batch of one) */
-		c->buf = (uint8_t *)malloc (c->cap);
+		c->buf = chunk_alloc (c->cap);
 		if (!c->buf) {
 			return NULL;
 		}
