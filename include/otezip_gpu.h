@@ -59,6 +59,9 @@ extern "C" {
 
 /* entry flags (in) */
 #define OZG_EF_IGNORE_ZIPBOMB 1u /* mirrors the global otezip_ignore_zipbomb */
+#define OZG_EF_SIZE_IS_CAP 2u   /* uncomp_size is the room, not the size: a Brotli stream (RFC 7932) or an end-marked LZMA1
+                                 * stream that ends before it is complete, total_out says where (the codec seam's calls:
+                                 * such a stream does not carry its length; a ZIP entry always does) */
 
 #define OZG_METHOD_STORE 0
 #define OZG_METHOD_DEFLATE 8

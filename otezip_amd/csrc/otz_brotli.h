@@ -824,11 +824,11 @@ OTZ_DEV bool otz_brotli_is_candidate(const u8 *in, u32 n_in) {
 
 // One method-97 entry (one work-item).  With a small arena, an entry whose tables do not fit is marked
 // OTZ_BR_ROUTE_AGAIN for the second pass.
-OTZ_DEV void otz_brotli_run(const u8 *in, u32 n_in, u8 *out, u32 cap, u8 *arena, u32 arena_bytes, const u8 *blob, ozg_result *res, u8 *route) {
+OTZ_DEV void otz_brotli_run(const u8 *in, u32 n_in, u8 *out, u32 cap, u32 eflags, u8 *arena, u32 arena_bytes, const u8 *blob, ozg_result *res, u8 *route) {
 	const otz_br_data D = otz_br_open (blob);
 	u32 total = 0;
 	const int st = otz_brotli_stream (in, n_in, out, cap, arena, arena_bytes, D, &total);
-	if (st == OZG_ST_OK && total == cap) {
+	if (st == OZG_ST_OK && (total == cap || (eflags & OZG_EF_SIZE_IS_CAP))) {
 		res->status = OZG_ST_OK;
 		res->total_out = total;
 		res->crc32 = 0;

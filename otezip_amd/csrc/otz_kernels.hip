@@ -224,7 +224,7 @@ otz_lzma_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *re
 			!otz_lzma_is_candidate (src + e.src_off, e.comp_size)) {
 			continue; // the copy kernel's (route stays 0)
 		}
-		otz_lzma_run (src + e.src_off, e.comp_size, dst + e.dst_off, e.uncomp_size, probs, &results[i], &route[i]);
+		otz_lzma_run (src + e.src_off, e.comp_size, dst + e.dst_off, e.uncomp_size, e.flags, probs, &results[i], &route[i]);
 	}
 }
 
@@ -249,7 +249,7 @@ otz_brotli_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *
 			!otz_brotli_is_candidate (src + e.src_off, e.comp_size)) {
 			continue; // the copy kernel's (route stays 0)
 		}
-		otz_brotli_run (src + e.src_off, e.comp_size, dst + e.dst_off, e.uncomp_size, mine, arena_bytes, blob, &results[i], &route[i]);
+		otz_brotli_run (src + e.src_off, e.comp_size, dst + e.dst_off, e.uncomp_size, e.flags, mine, arena_bytes, blob, &results[i], &route[i]);
 	}
 }
 

@@ -120,7 +120,7 @@ OTZ_DEV u32 otz_lzma_len(otz_lzma_rc &rc, u16 *lp, u32 pos_state) {
 
 // One stream.  in: the raw LZMA1 stream (behind the APPNOTE header); lc/lp/pb from the properties byte.
 // Decodes until `cap` bytes exist or the end marker appears.  Returns OZG_ST_OK (*total set) or OZG_ST_DATA.
-OTZ_DEV int otz_lzma_stream(const u8 *in, u32 n_in, u8 *out, u32 cap, u32 lc, u32 lpb, u32 pb, u16 *probs, u32 *total) {
+OTZ_DEV int otz_lzma_stream(const u8 *in, u32 n_in, u8 *out, u32 cap, u32 lc, u32 lpb, u32 pb, u16 *probs, u32 *total, bool *marked) {
 	const u32 nprobs = OTZ_LZ_LITERAL + (0x300u << (lc + lpb));
 	for (u32 i = 0; i < nprobs; i++) {
 		probs[i] = 1024;
@@ -257,7 +257,7 @@ OTZ_DEV int otz_lzma_stream(const u8 *in, u32 n_in, u8 *out, u32 cap, u32 lc, u3
 		}
 		pos += len;
 	}
-	(void)eos;
+	*marked = eos;
 	if (rc.over > 4u) { // (the coder reads up to four bytes ahead of the last bit it needs)
 		return OZG_ST_DATA;
 	}
@@ -271,17 +271,19 @@ OTZ_DEV bool otz_lzma_is_candidate(const u8 *in, u32 n_in) {
 }
 
 // One method-14 entry (one work-item).  probs: OTZ_LZMA_PROBS_MAX counters of scratch.
-OTZ_DEV void otz_lzma_run(const u8 *in, u32 n_in, u8 *out, u32 cap, u16 *probs, ozg_result *res, u8 *route) {
+OTZ_DEV void otz_lzma_run(const u8 *in, u32 n_in, u8 *out, u32 cap, u32 eflags, u16 *probs, ozg_result *res, u8 *route) {
 	u32 d = in[4];
 	const u32 lc = d % 9u;
 	d /= 9u;
 	const u32 lp = d % 5u, pb = d / 5u;
 	u32 total = 0;
+	bool marked = false;
 	int st = OZG_ST_DATA;
 	if (lc + lp <= 4u) { // (LZMA2's limit, and what every ZIP writer uses; more would not fit the scratch)
-		st = otz_lzma_stream (in + 9u, n_in - 9u, out, cap, lc, lp, pb, probs, &total);
+		st = otz_lzma_stream (in + 9u, n_in - 9u, out, cap, lc, lp, pb, probs, &total, &marked);
 	}
-	if (st == OZG_ST_OK && total == cap) {
+	// (with OZG_EF_SIZE_IS_CAP only the end marker can say where the stream ends)
+	if (st == OZG_ST_OK && (total == cap || ((eflags & OZG_EF_SIZE_IS_CAP) && marked))) {
 		res->status = OZG_ST_OK;
 		res->total_out = total;
 		res->crc32 = 0;

@@ -328,6 +328,36 @@ static int ozs_decode(z_stream *strm) {
 	uInt want = (uInt) (st->out_made + strm->avail_out);
 	/* (method 14 needs no look-ahead: its token reader stops by itself and the batch kernel
 	 * reports what it wrote even when that is not the size the entry announced) */
+	/* A Brotli stream (RFC 7932) and an LZMA1 stream behind the APPNOTE header do not say how long their
+	 * output is: the buffer is the room, the stream's own end (for LZMA1: its end marker) is the end.  What looks
+	 * like one is tried as one first; whatever that does not decode takes the reference's road below, with the
+	 * reference's verdicts (its readers do not look at the magic bytes: ref brotli.inc.c:154-171, lzma-dec.inc.c:216-232). */
+	const int real_brotli = st->method == OZG_METHOD_BROTLI && in_len >= 1 && !(in_len >= 4 && memcmp (in, "BROT", 4) == 0);
+	const int real_lzma = st->method == OZG_METHOD_LZMA && in_len >= 14 && in[2] == 5 && in[3] == 0;
+	if ((real_brotli || real_lzma) && st->out_made == 0) {
+		ozg_entry e;
+		memset (&e, 0, sizeof (e));
+		e.comp_size = (uint32_t)in_len;
+		e.uncomp_size = strm->avail_out;
+		e.method = (uint16_t)st->method;
+		e.flags = OZG_EF_IGNORE_ZIPBOMB | OZG_EF_SIZE_IS_CAP;
+		ozg_result r;
+		memset (&r, 0, sizeof (r));
+		const uint64_t out_len = ((uint64_t)e.uncomp_size + 15u) & ~(uint64_t)15u;
+		unsigned char *out = (unsigned char *)malloc (out_len ? out_len : 16);
+		if (!out) {
+			return Z_MEM_ERROR;
+		}
+		const int rc = ozg_decode_batch_host (in, in_len, out, out_len, &e, &r, 1);
+		if (rc == OZG_OK && r.status == OZG_ST_OK && r.total_out <= strm->avail_out) {
+			memcpy (strm->next_out, out, r.total_out);
+			ozs_advance (strm, strm->avail_in, r.total_out);
+			st->finished = 1;
+			free (out);
+			return Z_STREAM_END;
+		}
+		free (out);
+	}
 	if (st->method != OZG_METHOD_DEFLATE && st->method != OZG_METHOD_LZMA) {
 		long long plen = st->method == OZG_METHOD_ZSTD ? ozs_zstd_content_size (in, (uInt)in_len) : -1;
 		if (plen < 0) {

@@ -76,13 +76,13 @@ void *thread_main(void *p) {
 		// what otz_lzma_kernel does for one entry (one work-item)
 		const ozg_entry &e = *a->e;
 		if (otz_tid () == 0 && !otz_zipbomb (e, a->lim) && otz_lzma_is_candidate (a->src + e.src_off, e.comp_size)) {
-			otz_lzma_run (a->src + e.src_off, e.comp_size, a->dst + e.dst_off, e.uncomp_size, (u16 *)a->zs_lit, a->r, a->zs_route);
+			otz_lzma_run (a->src + e.src_off, e.comp_size, a->dst + e.dst_off, e.uncomp_size, e.flags, (u16 *)a->zs_lit, a->r, a->zs_route);
 		}
 	} else if (a->phase == 8) {
 		// what otz_brotli_kernel does for one entry (one work-item)
 		const ozg_entry &e = *a->e;
 		if (otz_tid () == 0 && !otz_zipbomb (e, a->lim) && otz_brotli_is_candidate (a->src + e.src_off, e.comp_size)) {
-			otz_brotli_run (a->src + e.src_off, e.comp_size, a->dst + e.dst_off, e.uncomp_size, a->zs_lit, a->region_bytes, g_brotli_blob, a->r, a->zs_route);
+			otz_brotli_run (a->src + e.src_off, e.comp_size, a->dst + e.dst_off, e.uncomp_size, e.flags, a->zs_lit, a->region_bytes, g_brotli_blob, a->r, a->zs_route);
 		}
 	} else if (a->phase == 5) {
 		// what otz_zstd_crc_kernel does

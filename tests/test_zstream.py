@@ -302,3 +302,34 @@ def test_inflate_goes_on_when_the_caller_makes_room(gpu_lib):
     assert s.total_in == len(blob) and s.avail_in == 0
     assert calls[0] >= 3 and calls[-5] >= 3
     assert L.inflateEnd(C.byref(s)) == 0
+
+
+@pytest.mark.gpu
+def test_real_brotli_and_lzma1_streams_through_the_seam(gpu_lib):
+    """brotliDecompress on a Brotli stream (RFC 7932) and lzmaDecompress on an APPNOTE 5.8.8 LZMA1 stream with an
+    end marker: such streams do not say how long their output is, the caller's buffer is the room
+    (OZG_EF_SIZE_IS_CAP) and total_out says where the stream ended.  Checked against libbrotli / liblzma."""
+    import lzma
+    import struct
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from otezip_amd import corpus
+    from tools import brotlilib as B
+    L = gpu_lib.lib()
+    datas = [b"", b"q", corpus.gen_text(4, 3000), corpus.gen_text(5, 70000), bytes(5000), b"xyz" * 3000]
+    for d in datas:
+        if B.available():
+            for q in (1, 5, 11):
+                comp = B.compress(d, quality=q)
+                ret, tin, tout, out = gpu_codec(L, "brotli", True, comp, len(d) + 777)
+                assert ret == 1 and tout == len(d) and out[:tout] == d, ("brotli", len(d), q, ret, tout)
+        f = [{"id": lzma.FILTER_LZMA1, "preset": 6, "lc": 3, "lp": 0, "pb": 2, "dict_size": 1 << 20}]
+        raw = lzma.compress(d, format=lzma.FORMAT_RAW, filters=f)  # (liblzma ends a raw stream with the end marker)
+        comp = b"\x09\x14\x05\x00" + bytes([(2 * 5 + 0) * 9 + 3]) + struct.pack("<I", 1 << 20) + raw
+        ret, tin, tout, out = gpu_codec(L, "lzma", True, comp, len(d) + 777)
+        assert ret == 1 and tout == len(d) and out[:tout] == d, ("lzma", len(d), ret, tout)
+    # a stream that needs more room than there is does not come out as a success
+    if B.available():
+        comp = B.compress(datas[3], quality=5)
+        ret, _, _, _ = gpu_codec(L, "brotli", True, comp, 1000)
+        assert ret != 1
