@@ -536,6 +536,7 @@ OTZ_DEV u32 otz_br_word(const otz_br_data &D, u32 len, u32 word_idx, u32 tr, u8 
 OTZ_DEV int otz_brotli_stream(const u8 *in, u32 n_in, u8 *out, u32 cap, u8 *arena_base, u32 arena_bytes, const otz_br_data &D, u32 *produced) {
 	otz_br_bits b = { in, n_in, 0, 0, 0 };
 	u32 pos = 0;
+	u32 p1 = 0, p2 = 0; // the last two bytes written (the literal context): kept in registers, not read back
 	*produced = 0;
 	// ---- stream header: WBITS
 	u32 wbits;
@@ -620,7 +621,10 @@ OTZ_DEV int otz_brotli_stream(const u8 *in, u32 n_in, u8 *out, u32 cap, u8 *aren
 				return OZG_ST_SIZE;
 			}
 			for (u32 i = 0; i < mlen; i++) {
-				out[pos++] = (u8)otz_br_read (b, 8);
+				const u32 v = otz_br_read (b, 8);
+				out[pos++] = (u8)v;
+				p2 = p1;
+				p1 = v;
 			}
 			if (otz_br_overrun (b)) {
 				return OZG_ST_DATA;
@@ -719,7 +723,6 @@ OTZ_DEV int otz_brotli_stream(const u8 *in, u32 n_in, u8 *out, u32 cap, u8 *aren
 					return OZG_ST_DATA;
 				}
 				cat[0].left--;
-				const u32 p1 = pos > 0 ? out[pos - 1u] : 0u, p2 = pos > 1u ? out[pos - 2u] : 0u;
 				const u8 *lut = D.ctx_lut + 512u * modes[cat[0].type];
 				const u32 ctx = lut[p1] | lut[256u + p2];
 				const u32 tree = cmap_l[64u * cat[0].type + ctx];
@@ -729,6 +732,8 @@ OTZ_DEV int otz_brotli_stream(const u8 *in, u32 n_in, u8 *out, u32 cap, u8 *aren
 					return OZG_ST_DATA;
 				}
 				out[pos++] = (u8)lit;
+				p2 = p1;
+				p1 = lit;
 			}
 			if (otz_br_overrun (b)) {
 				return OZG_ST_DATA;
@@ -780,8 +785,10 @@ OTZ_DEV int otz_brotli_stream(const u8 *in, u32 n_in, u8 *out, u32 cap, u8 *aren
 					return OZG_ST_DATA;
 				}
 				for (u32 i = 0; i < copy; i++) { // (byte by byte: the copy may overlap itself)
-					out[pos] = out[pos - dist];
-					pos++;
+					const u32 v = out[pos - dist];
+					out[pos++] = (u8)v;
+					p2 = p1;
+					p1 = v;
 				}
 				left -= copy;
 			} else {
@@ -801,6 +808,8 @@ OTZ_DEV int otz_brotli_stream(const u8 *in, u32 n_in, u8 *out, u32 cap, u8 *aren
 				}
 				pos += n;
 				left -= n;
+				p1 = pos > 0 ? out[pos - 1u] : 0u;
+				p2 = pos > 1u ? out[pos - 2u] : 0u;
 			}
 			if (otz_br_overrun (b)) {
 				return OZG_ST_DATA;
@@ -824,8 +833,12 @@ OTZ_DEV bool otz_brotli_is_candidate(const u8 *in, u32 n_in) {
 
 // One method-97 entry (one work-item).  With a small arena, an entry whose tables do not fit is marked
 // OTZ_BR_ROUTE_AGAIN for the second pass.
-OTZ_DEV void otz_brotli_run(const u8 *in, u32 n_in, u8 *out, u32 cap, u32 eflags, u8 *arena, u32 arena_bytes, const u8 *blob, ozg_result *res, u8 *route) {
-	const otz_br_data D = otz_br_open (blob);
+// ctx_lut (optional): a copy of the context lookup tables in faster memory than the blob (LDS).
+OTZ_DEV void otz_brotli_run(const u8 *in, u32 n_in, u8 *out, u32 cap, u32 eflags, u8 *arena, u32 arena_bytes, const u8 *blob, ozg_result *res, u8 *route, const u8 *ctx_lut = nullptr) {
+	otz_br_data D = otz_br_open (blob);
+	if (ctx_lut) {
+		D.ctx_lut = ctx_lut;
+	}
 	u32 total = 0;
 	const int st = otz_brotli_stream (in, n_in, out, cap, arena, arena_bytes, D, &total);
 	if (st == OZG_ST_OK && (total == cap || (eflags & OZG_EF_SIZE_IS_CAP))) {

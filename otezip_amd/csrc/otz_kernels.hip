@@ -235,6 +235,15 @@ extern "C" __global__ void __launch_bounds__ (64)
 otz_brotli_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *results, u32 n, u64 src_len, u64 dst_len, ozg_limits lim,
 	u8 *arena, u32 arena_bytes, const u8 *blob, u32 *cursor, u8 *route, u32 again) {
 	u8 *mine = arena + (size_t) (blockIdx.x * 64u + threadIdx.x) * arena_bytes;
+	// the literal context lookup (2 KB, read twice per literal) sits in LDS
+	__shared__ __attribute__ ((aligned (16))) u8 ctx_lut[2048];
+	{
+		const otz_br_data D = otz_br_open (blob);
+		for (u32 c = threadIdx.x; c < 2048u / 16u; c += 64u) {
+			*reinterpret_cast<otz_u4 *> (&ctx_lut[16u * c]) = otz_ld16 (D.ctx_lut + 16u * c);
+		}
+		otz_wave_sync_lds ();
+	}
 	for (;;) {
 		const u32 i = atomicAdd (cursor, 1u);
 		if (i >= n) {
@@ -249,7 +258,7 @@ otz_brotli_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *
 			!otz_brotli_is_candidate (src + e.src_off, e.comp_size)) {
 			continue; // the copy kernel's (route stays 0)
 		}
-		otz_brotli_run (src + e.src_off, e.comp_size, dst + e.dst_off, e.uncomp_size, e.flags, mine, arena_bytes, blob, &results[i], &route[i]);
+		otz_brotli_run (src + e.src_off, e.comp_size, dst + e.dst_off, e.uncomp_size, e.flags, mine, arena_bytes, blob, &results[i], &route[i], ctx_lut);
 	}
 }
 
