@@ -503,6 +503,9 @@ OTZ_DEV void otz_apply_entry(otz_apply_lds &L, const otz_job &J, const otz_ix_he
 			otz_sync ();
 			const u32 n = L.first_rej;
 			const u32 span_bits = L.flag;
+#ifdef OTZ_ST_PROF
+			OTZ_MARK (L, J, 1);
+#endif
 			if (n == 0 || blk->out_base + first.out != P.opos) {
 				otz_fail_all (L, OZG_ST_INTERNAL);
 				break;
@@ -511,6 +514,9 @@ OTZ_DEV void otz_apply_entry(otz_apply_lds &L, const otz_job &J, const otz_ix_he
 				L.last_out = z.out; // (read after the barriers of otz_place_items)
 			}
 			otz_a_stage (L, J, byte0, (((u32)abs0 & 7u) + span_bits + 7u) / 8u + 24u);
+#ifdef OTZ_ST_PROF
+			OTZ_MARK (L, J, 6);
+#endif
 			otz_a_begin (L, P);
 			otz_sync ();
 			OTZ_MARK (L, J, OTZ_P_STAGE);

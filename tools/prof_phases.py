@@ -11,7 +11,7 @@ import torch
 import otezip_amd as oz
 from otezip_amd import corpus, _native as N
 
-NAMES = ["res_busy#", "tb_rank", "tables", "stage", "far_go#", "tb_link", "tb_canon", "place", "flush", "tb_root", "resolve", "res_go#",
+NAMES = ["res_busy#", "tb_rank/st_items", "tables", "stage", "far_go#", "tb_link", "tb_canon/st_load", "place", "flush", "tb_root", "resolve", "res_go#",
          "rounds#", "B_iters#", "blocks#", "total"]
 
 
