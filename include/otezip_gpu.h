@@ -129,6 +129,8 @@ int ozg_decode_batch_device(const void *d_src, uint64_t src_len, void *d_dst, ui
                                    * a Zstandard frame per RFC 8878, or the reference's private raw-block framing) */
 #define OZG_BATCH_NO_BROTLI 16u   /* no entry is method 97: skip the Brotli kernel (a method-97 payload is sniffed: the
                                    * reference's "BROT" container, or a Brotli stream per RFC 7932) */
+#define OZG_BATCH_NO_LZFSE 32u    /* no entry is method 100: skip the LZFSE kernel (a method-100 payload is sniffed: the
+                                   * reference's 06 framing, or an LZFSE stream of bvx blocks -- parity unpinned) */
 int ozg_decode_batch_device_ex(const void *d_src, uint64_t src_len, void *d_dst, uint64_t dst_len,
 	const ozg_entry *d_entries, ozg_result *d_results, uint32_t n, void *stream, uint32_t batch_flags);
 

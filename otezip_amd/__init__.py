@@ -12,7 +12,7 @@ from ._native import (  # noqa: F401
     ST_OK, ST_NEED_OUT, ST_DATA, ST_BUF, ST_SIZE, ST_BOMB, ST_METHOD, ST_INTERNAL,
     F_REF_FALSE_REJECT, F_SHORT_STREAM, F_CRC_MISMATCH,
     METHOD_STORE, METHOD_DEFLATE, METHOD_LZMA, METHOD_ZSTD, METHOD_BROTLI, METHOD_LZFSE,
-    BATCH_ONLY_DEFLATE, BATCH_NO_DEFLATE, BATCH_NO_ZSTD, BATCH_NO_LZMA, BATCH_NO_BROTLI,
+    BATCH_ONLY_DEFLATE, BATCH_NO_DEFLATE, BATCH_NO_ZSTD, BATCH_NO_LZMA, BATCH_NO_BROTLI, BATCH_NO_LZFSE,
 )
 from .batch import Batch, decode_batch_host, encode_batch_host, make_entries  # noqa: F401
 

@@ -32,6 +32,7 @@
 #include "otz_zstd.h"
 #include "otz_lzma.h"
 #include "otz_brotli.h"
+#include "otz_lzfse.h"
 
 extern "C" const unsigned char otz_brotli_blob[], otz_brotli_blob_end[]; // otezip_amd/data/brotli_rfc7932.bin (brotli_data.S)
 
@@ -262,7 +263,29 @@ otz_brotli_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *
 	}
 }
 
-// CRC-32 of the entries otz_zstd_kernel / otz_lzma_kernel / otz_brotli_kernel decoded (ref src/lib/otezip.c:667-679)
+// LZFSE streams under method 100 (otz_lzfse.h): one work-item per stream, a persistent grid; the scratch is the
+// Brotli kernel's first-pass arena (OTZ_LZFSE_ARENA <= OTZ_BR_ARENA_SMALL per work-item; the two kernels run one
+// after the other on the batch's stream).
+static_assert (OTZ_LZFSE_ARENA <= OTZ_BR_ARENA_SMALL, "the LZFSE decoder's scratch fits the Brotli kernel's small arena");
+extern "C" __global__ void __launch_bounds__ (64)
+otz_lzfse_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *results, u32 n, u64 src_len, u64 dst_len, ozg_limits lim,
+	u8 *arena, u32 *cursor, u8 *route) {
+	u8 *mine = arena + (size_t) (blockIdx.x * 64u + threadIdx.x) * OTZ_BR_ARENA_SMALL;
+	for (;;) {
+		const u32 i = atomicAdd (cursor, 1u);
+		if (i >= n) {
+			break;
+		}
+		const ozg_entry e = entries[i];
+		if (e.method != OZG_METHOD_LZFSE || !otz_entry_in_bounds (e, src_len, dst_len) || otz_zipbomb (e, lim) ||
+			!otz_lzfse_is_candidate (src + e.src_off, e.comp_size)) {
+			continue; // the copy kernel's (route stays 0)
+		}
+		otz_lzfse_run (src + e.src_off, e.comp_size, dst + e.dst_off, e.uncomp_size, e.flags, mine, &results[i], &route[i]);
+	}
+}
+
+// CRC-32 of the entries otz_zstd_kernel / otz_lzma_kernel / otz_brotli_kernel / otz_lzfse_kernel decoded (ref src/lib/otezip.c:667-679)
 extern "C" __global__ void __launch_bounds__ (256)
 otz_zstd_crc_kernel(u8 *dst, const ozg_entry *entries, ozg_result *results, u32 n, const u8 *route) {
 	extern __shared__ __attribute__ ((aligned (16))) u8 otz_smem[];
@@ -837,7 +860,8 @@ int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, 
 	if (!(batch_flags & OZG_BATCH_ONLY_DEFLATE)) {
 		const u8 *route = nullptr;
 		const bool want_zs = !(batch_flags & OZG_BATCH_NO_ZSTD), want_lz = !(batch_flags & OZG_BATCH_NO_LZMA), want_br = !(batch_flags & OZG_BATCH_NO_BROTLI);
-		if (want_zs || want_lz || want_br) {
+		const bool want_lf = !(batch_flags & OZG_BATCH_NO_LZFSE);
+		if (want_zs || want_lz || want_br || want_lf) {
 			// methods 93 and 14: the real formats first (the rest of the batch, and what turns out not to
 			// be one of them, is the copy kernel's)
 			workspace &ws = C.ws;
@@ -852,7 +876,7 @@ int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, 
 				OZG_HIP (hipMalloc ((void **)&ws.lz_cursor, 256));
 				OZG_HIP (hipMalloc ((void **)&ws.br_cursor, 256));
 			}
-			if ((want_zs && grid > ws.zs_grid) || n > ws.zs_route_cap || (want_lz && lz_threads > ws.lz_threads) || (want_br && br_threads > ws.br_threads)) {
+			if ((want_zs && grid > ws.zs_grid) || n > ws.zs_route_cap || (want_lz && lz_threads > ws.lz_threads) || ((want_br || want_lf) && br_threads > ws.br_threads)) {
 				OZG_HIP (hipDeviceSynchronize ()); // an earlier batch may still use what is about to be freed
 				ws.busy = false;
 			}
@@ -872,7 +896,7 @@ int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, 
 				OZG_HIP (hipMalloc ((void **)&ws.lz_probs, (size_t)t * OTZ_LZMA_PROB_BYTES));
 				ws.lz_threads = t;
 			}
-			if (want_br && br_threads > ws.br_threads) {
+			if ((want_br || want_lf) && br_threads > ws.br_threads) {
 				(void)hipFree (ws.br_arena);
 				ws.br_arena = nullptr;
 				ws.br_threads = 0;
@@ -901,7 +925,7 @@ int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, 
 			}
 			OZG_HIP (hipMemsetAsync (ws.zs_cursor, 0, 4, s));
 			OZG_HIP (hipMemsetAsync (ws.lz_cursor, 0, 4, s));
-			OZG_HIP (hipMemsetAsync (ws.br_cursor, 0, 8, s)); // (one counter per pass)
+			OZG_HIP (hipMemsetAsync (ws.br_cursor, 0, 12, s)); // (one counter per Brotli pass, one for LZFSE)
 			OZG_HIP (hipMemsetAsync (ws.zs_route, 0, n, s));
 			if (want_zs) {
 				if (g_prof) {
@@ -926,6 +950,11 @@ int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, 
 					(u64)src_len, (u64)dst_len, g_limits, ws.br_big, OTZ_BR_ARENA, (const u8 *)ws.br_blob, ws.br_cursor + 1, ws.zs_route, 1u);
 				OZG_HIP (hipGetLastError ());
 			}
+			if (want_lf) {
+				hipLaunchKernelGGL (otz_lzfse_kernel, dim3 (br_threads / 64u), dim3 (64), 0, s, (const u8 *)d_src, (u8 *)d_dst, d_entries, d_results, n,
+					(u64)src_len, (u64)dst_len, g_limits, ws.br_arena, ws.br_cursor + 2, ws.zs_route);
+				OZG_HIP (hipGetLastError ());
+			}
 			route = ws.zs_route;
 		}
 		hipLaunchKernelGGL (otz_copy_kernel, dim3 (n), dim3 (256), sizeof (otz_copy_lds), s, (const u8 *)d_src,
@@ -943,7 +972,7 @@ int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, 
 
 // host-side view of a descriptor table: bounds, and which launches it needs
 int check_entries(const ozg_entry *entries, uint32_t n, uint64_t src_len, uint64_t dst_len, uint32_t *flags) {
-	uint32_t f = OZG_BATCH_NO_DEFLATE | OZG_BATCH_ONLY_DEFLATE | OZG_BATCH_NO_ZSTD | OZG_BATCH_NO_LZMA | OZG_BATCH_NO_BROTLI;
+	uint32_t f = OZG_BATCH_NO_DEFLATE | OZG_BATCH_ONLY_DEFLATE | OZG_BATCH_NO_ZSTD | OZG_BATCH_NO_LZMA | OZG_BATCH_NO_BROTLI | OZG_BATCH_NO_LZFSE;
 	for (uint32_t i = 0; i < n; i++) {
 		const ozg_entry &e = entries[i];
 		if (e.src_off > src_len || e.comp_size > src_len - e.src_off || (e.dst_off & 15u) || e.dst_off > dst_len ||
@@ -960,6 +989,9 @@ int check_entries(const ozg_entry *entries, uint32_t n, uint64_t src_len, uint64
 		}
 		if (e.method == OZG_METHOD_BROTLI) {
 			f &= ~OZG_BATCH_NO_BROTLI;
+		}
+		if (e.method == OZG_METHOD_LZFSE) {
+			f &= ~OZG_BATCH_NO_LZFSE;
 		}
 	}
 	*flags = f;

@@ -9,6 +9,7 @@
 #include "otz_zstd.h"
 #include "otz_lzma.h"
 #include "otz_brotli.h"
+#include "otz_lzfse.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -83,6 +84,12 @@ void *thread_main(void *p) {
 		const ozg_entry &e = *a->e;
 		if (otz_tid () == 0 && !otz_zipbomb (e, a->lim) && otz_brotli_is_candidate (a->src + e.src_off, e.comp_size)) {
 			otz_brotli_run (a->src + e.src_off, e.comp_size, a->dst + e.dst_off, e.uncomp_size, e.flags, a->zs_lit, a->region_bytes, g_brotli_blob, a->r, a->zs_route);
+		}
+	} else if (a->phase == 9) {
+		// what otz_lzfse_kernel does for one entry (one work-item)
+		const ozg_entry &e = *a->e;
+		if (otz_tid () == 0 && !otz_zipbomb (e, a->lim) && otz_lzfse_is_candidate (a->src + e.src_off, e.comp_size)) {
+			otz_lzfse_run (a->src + e.src_off, e.comp_size, a->dst + e.dst_off, e.uncomp_size, e.flags, a->zs_lit, a->r, a->zs_route);
 		}
 	} else if (a->phase == 5) {
 		// what otz_zstd_crc_kernel does
@@ -286,6 +293,23 @@ extern "C" int emu_decode_batch_mode(const void *src, uint64_t src_len, void *ds
 			a.zs_lit = probs.data ();
 			a.zs_route = &route;
 			a.phase = 6;
+			run_block (64, a, 64);
+			a.phase = 0;
+			if (route != OTZ_ZS_ROUTE_DONE) {
+				run_block (OTZ_CNT, a, lds_bytes);
+			} else if (results[i].status == OZG_ST_OK) {
+				a.phase = 5;
+				run_block (OTZ_CNT, a, lds_bytes);
+			}
+			continue;
+		}
+		if (entries[i].method == OZG_METHOD_LZFSE) {
+			// product order: LZFSE kernel, copy kernel (the reference's 06 framing) unless it decoded the entry, CRC pass
+			std::vector<u8> arena (OTZ_BR_ARENA_SMALL + 16, 0xA5);
+			u8 route = 0;
+			a.zs_lit = (u8 *) (((uintptr_t)arena.data () + 15u) & ~(uintptr_t)15u);
+			a.zs_route = &route;
+			a.phase = 9;
 			run_block (64, a, 64);
 			a.phase = 0;
 			if (route != OTZ_ZS_ROUTE_DONE) {
