@@ -74,23 +74,26 @@ def main():
     try:  # the other two real formats: Brotli streams and LZMA1 (one work-item per stream: thousands of streams per launch)
         arc_br, ents_br = zstd_corpus.build_brotli_real(n, 65536)
         arc_lz, ents_lz = zstd_corpus.build_lzma_real(n, 65536)
+        arc_lf, ents_lf = zstd_corpus.build_lzfse_real(min(n, 4000), 65536)
     except Exception as ex:
         print("real Brotli / LZMA corpus unavailable: %r" % (ex,), file=sys.stderr)
     oz.init(0)
     L = oz.lib()
     dev = torch.device("cuda", 0)
-    report["zstd93_256KiB_decode"] = decode_resident(arc_z, ents_z, oz.BATCH_NO_DEFLATE | oz.BATCH_NO_LZMA | oz.BATCH_NO_BROTLI)
+    report["zstd93_256KiB_decode"] = decode_resident(arc_z, ents_z, oz.BATCH_NO_DEFLATE | oz.BATCH_NO_LZMA | oz.BATCH_NO_BROTLI | oz.BATCH_NO_LZFSE)
     report["lzfse100_brot97_64KiB_decode"] = decode_resident(arc_m, ents_m, oz.BATCH_NO_DEFLATE | oz.BATCH_NO_ZSTD | oz.BATCH_NO_LZMA)
     if arc_rz is not None:
-        report["zstd_rfc8878_256KiB_decode"] = dict(decode_resident(arc_rz, ents_rz, oz.BATCH_NO_DEFLATE | oz.BATCH_NO_LZMA | oz.BATCH_NO_BROTLI), entries=len(ents_rz),
+        report["zstd_rfc8878_256KiB_decode"] = dict(decode_resident(arc_rz, ents_rz, oz.BATCH_NO_DEFLATE | oz.BATCH_NO_LZMA | oz.BATCH_NO_BROTLI | oz.BATCH_NO_LZFSE), entries=len(ents_rz),
                                                       note="real Zstandard frames, libzstd level 3 with content checksum")
-        report["zstd_rfc8878_64KiB_decode"] = dict(decode_resident(arc_rz64, ents_rz64, oz.BATCH_NO_DEFLATE | oz.BATCH_NO_LZMA | oz.BATCH_NO_BROTLI), entries=len(ents_rz64),
+        report["zstd_rfc8878_64KiB_decode"] = dict(decode_resident(arc_rz64, ents_rz64, oz.BATCH_NO_DEFLATE | oz.BATCH_NO_LZMA | oz.BATCH_NO_BROTLI | oz.BATCH_NO_LZFSE), entries=len(ents_rz64),
                                                      note="real Zstandard frames, libzstd level 3 with content checksum")
     if arc_br is not None:
-        report["brotli_rfc7932_64KiB_decode"] = dict(decode_resident(arc_br, ents_br, oz.BATCH_NO_DEFLATE | oz.BATCH_NO_ZSTD | oz.BATCH_NO_LZMA),
+        report["brotli_rfc7932_64KiB_decode"] = dict(decode_resident(arc_br, ents_br, oz.BATCH_NO_DEFLATE | oz.BATCH_NO_ZSTD | oz.BATCH_NO_LZMA | oz.BATCH_NO_LZFSE),
                                                      entries=len(ents_br), note="real Brotli streams, libbrotlienc quality 5, window 22")
-        report["lzma1_appnote_64KiB_decode"] = dict(decode_resident(arc_lz, ents_lz, oz.BATCH_NO_DEFLATE | oz.BATCH_NO_ZSTD | oz.BATCH_NO_BROTLI),
+        report["lzma1_appnote_64KiB_decode"] = dict(decode_resident(arc_lz, ents_lz, oz.BATCH_NO_DEFLATE | oz.BATCH_NO_ZSTD | oz.BATCH_NO_BROTLI | oz.BATCH_NO_LZFSE),
                                                     entries=len(ents_lz), note="APPNOTE 5.8.8 LZMA1, liblzma preset 1, lc3 lp0 pb2")
+        report["lzfse_model_64KiB_decode"] = dict(decode_resident(arc_lf, ents_lf, oz.BATCH_NO_DEFLATE | oz.BATCH_NO_ZSTD | oz.BATCH_NO_LZMA | oz.BATCH_NO_BROTLI),
+                                                  entries=len(ents_lf), note="LZFSE streams (bvx2 blocks) written by tools/lzfse_model.py: parity unpinned")
     # encode, resident
     nb = len(bufs)
     ents = (N.OzgEncEntry * nb)()

@@ -28,6 +28,7 @@ def main():
     try:
         zstd_corpus.build_brotli_real(n, 65536)
         zstd_corpus.build_lzma_real(n, 65536)
+        zstd_corpus.build_lzfse_real(min(n, 4000), 65536)
     except Exception as ex:
         print("real Brotli / LZMA corpus unavailable: %r" % (ex,))
     print("corpora cached")

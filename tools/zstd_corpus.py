@@ -49,6 +49,13 @@ def _lzma_one(args):
     return idx, 14, payload, len(data), zlib.crc32(data) & 0xFFFFFFFF
 
 
+def _lzfse_one(args):
+    from tools import lzfse_model as M
+    idx, size, kind = args
+    data = corpus.gen_text(idx, size)
+    return idx, 100, M.encode(data, ("lzfse", "lzvn")[kind]), len(data), zlib.crc32(data) & 0xFFFFFFFF
+
+
 def _build(tag, one, n, size, knob, first, workers):
     def make():
         jobs = [(first + i, size, knob) for i in range(n)]
@@ -70,3 +77,9 @@ def build_brotli_real(n, size, quality=5, first=0, workers=None):
 def build_lzma_real(n, size, preset=1, first=0, workers=None):
     """(archive_bytes, entries): method-14 payloads are APPNOTE 5.8.8 headers + raw LZMA1 streams from liblzma."""
     return _build("lzmareal", _lzma_one, n, size, preset, first, workers)
+
+
+def build_lzfse_real(n, size, kind=0, first=0, workers=None):
+    """(archive_bytes, entries): method-100 payloads are LZFSE streams as tools/lzfse_model.py writes them (kind 0:
+    bvx2 blocks, 1: LZVN) -- a model of the format, parity unpinned."""
+    return _build("lzfsereal", _lzfse_one, n, size, kind, first, workers)
