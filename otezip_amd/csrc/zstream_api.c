@@ -334,7 +334,8 @@ static int ozs_decode(z_stream *strm) {
 	 * reference's verdicts (its readers do not look at the magic bytes: ref brotli.inc.c:154-171, lzma-dec.inc.c:216-232). */
 	const int real_brotli = st->method == OZG_METHOD_BROTLI && in_len >= 1 && !(in_len >= 4 && memcmp (in, "BROT", 4) == 0);
 	const int real_lzma = st->method == OZG_METHOD_LZMA && in_len >= 14 && in[2] == 5 && in[3] == 0;
-	if ((real_brotli || real_lzma) && st->out_made == 0) {
+	const int real_lzfse = st->method == OZG_METHOD_LZFSE && in_len >= 4 && memcmp (in, "bvx", 3) == 0; /* (its end block says where it ends) */
+	if ((real_brotli || real_lzma || real_lzfse) && st->out_made == 0) {
 		ozg_entry e;
 		memset (&e, 0, sizeof (e));
 		e.comp_size = (uint32_t)in_len;

@@ -305,9 +305,9 @@ def test_inflate_goes_on_when_the_caller_makes_room(gpu_lib):
 
 
 @pytest.mark.gpu
-def test_real_brotli_and_lzma1_streams_through_the_seam(gpu_lib):
-    """brotliDecompress on a Brotli stream (RFC 7932) and lzmaDecompress on an APPNOTE 5.8.8 LZMA1 stream with an
-    end marker: such streams do not say how long their output is, the caller's buffer is the room
+def test_real_brotli_lzma1_and_lzfse_streams_through_the_seam(gpu_lib):
+    """brotliDecompress on a Brotli stream (RFC 7932), lzmaDecompress on an APPNOTE 5.8.8 LZMA1 stream with an
+    end marker, lzfseDecompress on an LZFSE stream: such streams do not say how long their output is, the caller's buffer is the room
     (OZG_EF_SIZE_IS_CAP) and total_out says where the stream ended.  Checked against libbrotli / liblzma."""
     import lzma
     import struct
@@ -328,6 +328,10 @@ def test_real_brotli_and_lzma1_streams_through_the_seam(gpu_lib):
         comp = b"\x09\x14\x05\x00" + bytes([(2 * 5 + 0) * 9 + 3]) + struct.pack("<I", 1 << 20) + raw
         ret, tin, tout, out = gpu_codec(L, "lzma", True, comp, len(d) + 777)
         assert ret == 1 and tout == len(d) and out[:tout] == d, ("lzma", len(d), ret, tout)
+        from tools import lzfse_model as M
+        for kind in ("lzvn", "lzfse", "mixed"):   # (LZFSE: checked against the model of the format, parity unpinned)
+            ret, tin, tout, out = gpu_codec(L, "lzfse", True, M.encode(d, kind), len(d) + 777)
+            assert ret == 1 and tout == len(d) and out[:tout] == d, ("lzfse", kind, len(d), ret, tout)
     # a stream that needs more room than there is does not come out as a success
     if B.available():
         comp = B.compress(datas[3], quality=5)
