@@ -971,7 +971,11 @@ int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, 
 }
 
 // host-side view of a descriptor table: bounds, and which launches it needs
-int check_entries(const ozg_entry *entries, uint32_t n, uint64_t src_len, uint64_t dst_len, uint32_t *flags) {
+// h_src (optional): the payloads, when they are in host memory -- then the kernels of the real formats (Zstandard,
+// LZMA1, Brotli, LZFSE) are only asked for when some payload LOOKS like one (the same first-bytes tests the
+// kernels make: otz_*_is_candidate), not merely because an entry has the method id: an archive of the
+// reference's own framings launches none of them and allocates none of their scratch.
+int check_entries(const ozg_entry *entries, uint32_t n, uint64_t src_len, uint64_t dst_len, uint32_t *flags, const uint8_t *h_src = nullptr) {
 	uint32_t f = OZG_BATCH_NO_DEFLATE | OZG_BATCH_ONLY_DEFLATE | OZG_BATCH_NO_ZSTD | OZG_BATCH_NO_LZMA | OZG_BATCH_NO_BROTLI | OZG_BATCH_NO_LZFSE;
 	for (uint32_t i = 0; i < n; i++) {
 		const ozg_entry &e = entries[i];
@@ -981,16 +985,21 @@ int check_entries(const ozg_entry *entries, uint32_t n, uint64_t src_len, uint64
 			return OZG_E_ARG;
 		}
 		f &= e.method == OZG_METHOD_DEFLATE ? ~OZG_BATCH_NO_DEFLATE : ~OZG_BATCH_ONLY_DEFLATE;
+		const uint8_t *p = h_src ? h_src + e.src_off : nullptr;
+		const uint32_t m = e.comp_size;
 		if (e.method == OZG_METHOD_ZSTD) {
-			f &= ~OZG_BATCH_NO_ZSTD;
+			const uint32_t magic = p && m >= 5u ? (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24) : 0u;
+			if (!p || (m >= 5u && ((magic & 0xFFFFFFF0u) == 0x184D2A50u || (magic == 0xFD2FB528u && (p[4] & 0x10u) == 0)))) {
+				f &= ~OZG_BATCH_NO_ZSTD;
+			}
 		}
-		if (e.method == OZG_METHOD_LZMA) {
+		if (e.method == OZG_METHOD_LZMA && (!p || (m >= 14u && p[2] == 5u && p[3] == 0 && p[4] < 225u))) {
 			f &= ~OZG_BATCH_NO_LZMA;
 		}
-		if (e.method == OZG_METHOD_BROTLI) {
+		if (e.method == OZG_METHOD_BROTLI && (!p || (m >= 1u && !(m >= 4u && p[0] == 'B' && p[1] == 'R' && p[2] == 'O' && p[3] == 'T')))) {
 			f &= ~OZG_BATCH_NO_BROTLI;
 		}
-		if (e.method == OZG_METHOD_LZFSE) {
+		if (e.method == OZG_METHOD_LZFSE && (!p || (m >= 4u && p[0] == 'b' && p[1] == 'v' && p[2] == 'x'))) {
 			f &= ~OZG_BATCH_NO_LZFSE;
 		}
 	}
@@ -1192,7 +1201,7 @@ int ozg_decode_batch_host_ex(const void *src, uint64_t src_len, void *dst, uint6
 		return OZG_E_ARG;
 	}
 	uint32_t flags;
-	if ((rc = check_entries (entries, n, src_len, dst_len, &flags)) != OZG_OK) {
+	if ((rc = check_entries (entries, n, src_len, dst_len, &flags, (const uint8_t *)src)) != OZG_OK) {
 		return rc;
 	}
 	std::lock_guard<std::mutex> lk (g_mu);
@@ -1249,7 +1258,7 @@ int ozg_decode_submit(const void *h_src, uint64_t src_len, void *h_dst, uint64_t
 		return OZG_E_ARG;
 	}
 	uint32_t flags;
-	if ((rc = check_entries (entries, n, src_len, dst_len, &flags)) != OZG_OK) {
+	if ((rc = check_entries (entries, n, src_len, dst_len, &flags, (const uint8_t *)h_src)) != OZG_OK) {
 		return rc;
 	}
 	std::lock_guard<std::mutex> lk (g_mu);
