@@ -9,6 +9,7 @@ ROOT = os.path.dirname(HERE)
 ST_OK, ST_NEED_OUT, ST_DATA, ST_BUF, ST_SIZE, ST_BOMB, ST_METHOD, ST_INTERNAL = 1, 0, -3, -5, -20, -21, -22, -30
 F_REF_FALSE_REJECT, F_SHORT_STREAM, F_CRC_MISMATCH = 1, 2, 4
 METHOD_STORE, METHOD_DEFLATE, METHOD_LZMA, METHOD_ZSTD, METHOD_BROTLI, METHOD_LZFSE = 0, 8, 14, 93, 97, 100
+EF_IGNORE_ZIPBOMB, EF_SIZE_IS_CAP = 1, 2  # ozg_entry.flags
 BATCH_ONLY_DEFLATE, BATCH_NO_DEFLATE, BATCH_NO_ZSTD, BATCH_NO_LZMA, BATCH_NO_BROTLI, BATCH_NO_LZFSE = 1, 2, 4, 8, 16, 32
 
 
