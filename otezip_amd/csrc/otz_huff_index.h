@@ -348,7 +348,9 @@ OTZ_DEV int otz_k1_build_tables(otz_k1_lds &L, u32 hlit, u32 hdist) {
 			const u32 l = sym < nsym ? L.h.ll[at0 + sym] : 0u;
 			const u32 before = otz_shfl (cnt, l);
 			u32 rank = 0;
-			for (u32 k = 1; k <= 15u; k++) {
+			u64 rem = otz_ballot (l != 0); // one ballot per code length that occurs in this chunk
+			while (rem != 0) {
+				const u32 k = otz_readlane (l, otz_ctz64 (rem));
 				const u64 m = otz_ballot (l == k);
 				if (l == k) {
 					rank = otz_popc64 (m & below);
@@ -356,6 +358,7 @@ OTZ_DEV int otz_k1_build_tables(otz_k1_lds &L, u32 hlit, u32 hdist) {
 				if (lane == k) {
 					cnt += otz_popc64 (m);
 				}
+				rem &= ~m;
 			}
 			if (sym < nsym) {
 				L.h.rank[at0 + sym] = (u16) (before + rank);
@@ -379,11 +382,24 @@ OTZ_DEV int otz_k1_build_tables(otz_k1_lds &L, u32 hlit, u32 hdist) {
 			const u32 sym = base + lane;
 			const u32 l = sym < nsym ? L.h.ll[at0 + sym] : 0u;
 			const u32 f = otz_shfl (first, l);
+			u32 rr = 0, e = 0;
 			if (l && l <= root) {
-				const u32 rr = otz_brev (f + L.h.rank[at0 + sym]) >> (32u - l);
-				const u16 e = (u16) (tbl ? otz_k1_mk_dist (sym, l) : otz_k1_mk_lit (sym, l));
-				for (u32 idx = rr; idx < rsz; idx += 1u << l) {
-					lut[idx] = e;
+				rr = otz_brev (f + L.h.rank[at0 + sym]) >> (32u - l);
+				e = tbl ? otz_k1_mk_dist (sym, l) : otz_k1_mk_lit (sym, l);
+				if (l + 5u > root) {
+					for (u32 idx = rr; idx < rsz; idx += 1u << l) { // at most sixteen root slots
+						lut[idx] = (u16)e;
+					}
+				}
+			}
+			// a very short code owns 32 root slots or more: the wavefront fills those together, a symbol at a time
+			u64 heavy = otz_ballot (l != 0 && l + 5u <= root);
+			while (heavy != 0) {
+				const u32 hs = otz_ctz64 (heavy);
+				heavy &= heavy - 1u;
+				const u32 ls = otz_readlane (l, hs), rs = otz_readlane (rr, hs), es = otz_readlane (e, hs);
+				for (u32 idx = rs + (lane << ls); idx < rsz; idx += 64u << ls) {
+					lut[idx] = (u16)es;
 				}
 			}
 		}

@@ -485,15 +485,22 @@ OTZ_DEV bool otz_build_tables(LDS &L, u32 hlit, u32 hdist) {
 	}
 	u32 rank = 0; // symbols of the same length before this one in its wavefront
 	if (wave < 6u) {
+		// one ballot per code length that occurs in this wavefront (typically 4-8 of the 15)
 		const u64 below = ((u64)1 << lane) - 1u;
-		for (u32 k = 1; k <= 15u; k++) {
-			u64 m = otz_ballot (l == k);
+		if (lane < 16u) {
+			L.wcnt[wave][lane] = 0; // (the counts below come from the same wavefront: LDS keeps its order)
+		}
+		u64 rem = otz_ballot (l != 0);
+		while (rem != 0) {
+			const u32 k = otz_readlane (l, otz_ctz64 (rem));
+			const u64 m = otz_ballot (l == k);
 			if (l == k) {
 				rank = otz_popc64 (m & below);
 			}
 			if (lane == 0) {
 				L.wcnt[wave][k] = otz_popc64 (m);
 			}
+			rem &= ~m;
 		}
 	}
 	otz_sync ();
@@ -548,12 +555,26 @@ OTZ_DEV bool otz_build_tables(LDS &L, u32 hlit, u32 hdist) {
 		}
 		rr = otz_brev ((u32)c.first[l] + before) >> (32u - l);
 		e = is_dist ? otz_mk_dist_entry (sym, l) : otz_mk_lit_entry (sym, l);
-		if (l <= root) {
-			for (u32 idx = rr; idx < rsz; idx += 1u << l) {
+		if (l > root) {
+			otz_lds_max (&lut[rr & (rsz - 1u)], (l - root) << 8); // widest code under this root slot
+		} else if (l + 5u > root) {
+			for (u32 idx = rr; idx < rsz; idx += 1u << l) { // at most sixteen root slots
 				lut[idx] = e;
 			}
-		} else {
-			otz_lds_max (&lut[rr & (rsz - 1u)], (l - root) << 8); // widest code under this root slot
+		}
+	}
+	if (wave < 6u) {
+		// A very short code owns many root slots (a 4-bit literal code 32 of the 512): the wavefront fills those
+		// together, a symbol at a time, instead of waiting for the lane that owns the most.  (lut, root and rsz
+		// are the same for all lanes of a wavefront: the distance symbols have wavefront 5 to themselves.)
+		u64 heavy = otz_ballot (l != 0 && l + 5u <= root);
+		while (heavy != 0) {
+			const u32 s = otz_ctz64 (heavy);
+			heavy &= heavy - 1u;
+			const u32 ls = otz_readlane (l, s), rs = otz_readlane (rr, s), es = otz_readlane (e, s);
+			for (u32 idx = rs + (lane << ls); idx < rsz; idx += 64u << ls) {
+				lut[idx] = es;
+			}
 		}
 	}
 	otz_sync ();
