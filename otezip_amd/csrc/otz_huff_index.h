@@ -238,15 +238,16 @@ OTZ_DEV int otz_k1_parse_lengths(otz_k1_lds &L, u32 p, u64 avail, u32 n, u32 *bi
 		u64 starts = 0;
 		u32 cur = 0, got = idx;
 		bool fail = false;
+		const u32 tokw = nb | (cnt << 8); // (one cross-lane read per token of the chain: bits taken | lengths made)
 		while (cur < 64u && got < n) {
-			const u32 step = otz_readlane (nb, cur);
-			const u32 c = otz_readlane (cnt, cur);
+			const u32 t = otz_readlane (tokw, cur);
+			const u32 step = t & 0xFFu;
 			if (step == 0) {
 				fail = true;
 				break;
 			}
 			starts |= (u64)1 << cur;
-			got += c;
+			got += t >> 8;
 			cur += step;
 		}
 		if (fail || got > n) { // bad code, out of input, or a run past hlit + hdist
