@@ -1018,6 +1018,9 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 				if (otz_ballot (acc && nB_items != 0) != 0) {
 #pragma unroll 2
 					for (u32 r = 0; r < OTZ_K1_ROWS; r++) {
+						if (otz_ballot (acc && r < nB_items) == 0) {
+							break; // (no lane has that many rows)
+						}
 						if (acc && r < nB_items) {
 							otz_ix_item it = rowsB[r * 64u + otz_opaque (lane)];
 							it.bit += bit0;
@@ -1034,6 +1037,9 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 				}
 #pragma unroll 4
 				for (u32 r = 1; r < OTZ_K1_ROWS; r++) {
+					if (otz_ballot (acc && tailA && r < nckA) == 0) {
+						break; // (walk A's paths are shorter than that)
+					}
 					if (acc && tailA && r >= rA0 && r < nckA) {
 						otz_ix_item it = rowsA[r * 64u + otz_opaque (lane)];
 						it.bit += bit0;
