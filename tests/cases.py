@@ -102,7 +102,8 @@ def deflate_fuzz(seed=4, n=120):
 
 
 def deflate_large(seed=5):
-    """Entries beyond the 64 KiB LDS ring (mid-entry flushes) and multi-round blocks."""
+    """Entries of several rounds and more than one 32 KiB window (what the fallback routine's LDS ring flushes
+    in mid-entry, and what the apply kernel writes out round by round), multi-round blocks."""
     r = _rng(seed)
     out = []
     for n in (65536, 65537, 100000, 300000):
@@ -116,9 +117,10 @@ def deflate_large(seed=5):
 
 
 def deflate_ring_wrap(seed=7, ring=57344):
-    """Overlapping matches (distance < copy chunk) whose first period straddles the end of
-    the kernel's output ring (OTZ_RING bytes): the copy has to split at the wrap without
-    losing the period."""
+    """Overlapping matches (distance < copy chunk) whose first period straddles the end of the
+    fallback routine's output ring (OTZ_RING bytes: the copy has to split at the wrap without
+    losing the period) -- for the apply kernel, which keeps a linear round buffer, the same streams put
+    such matches next to a round's start, where the source is partly behind the buffer."""
     r = _rng(seed)
     out = []
     for k, period in ((1, 7), (2, 3), (5, 9), (1, 2), (3, 15), (0, 1), (8, 13)):

@@ -53,12 +53,12 @@ def test_deflate_fuzz_never_hangs_or_overruns():
     _run(cases.deflate_fuzz(n=60))
 
 
-def test_deflate_beyond_the_lds_ring():
+def test_deflate_entries_of_many_rounds():
     items = cases.deflate_large()
-    _run([items[0], items[2]])  # 64 KiB and 100 000 B of text: several rounds, two flushes
+    _run([items[0], items[2]])  # 64 KiB and 100 000 B of text: several rounds, the window slides
 
 
-def test_deflate_overlapping_matches_across_the_ring_end():
+def test_deflate_overlapping_matches_at_buffer_boundaries():
     _run(cases.deflate_ring_wrap())
 
 
