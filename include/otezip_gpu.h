@@ -151,9 +151,9 @@ int ozg_decode_batch_host_ex(const void *src, uint64_t src_len, void *dst, uint6
  * copies, the kernels and the D2H copies on a stream of its own and returns at once.  h_src,
  * h_dst and h_results should come from ozg_malloc_pinned (pageable memory works, but then the
  * copies are not asynchronous); they must stay valid until the job has been waited for; the
- * descriptor table is copied.  At most three jobs per device are in flight (OZG_E_NOMEM
- * beyond that).  ozg_job_wait blocks until outputs and results are in host memory and
- * releases the job; ozg_job_done polls. */
+ * descriptor table is copied.  At most eight jobs per device are in flight (OZG_E_NOMEM
+ * beyond that: back-pressure, not failure).  ozg_job_wait blocks until outputs and results are in host
+ * memory and releases the job; ozg_job_done polls (1: a wait would not block) and never releases. */
 typedef struct ozg_job ozg_job;
 int ozg_decode_submit(const void *h_src, uint64_t src_len, void *h_dst, uint64_t dst_len,
 	const ozg_entry *entries, ozg_result *h_results, uint32_t n, ozg_job **job);
@@ -207,7 +207,9 @@ int ozg_encode_submit(const void *h_src, uint64_t src_len, void *h_dst, uint64_t
  * payload of entry i starts at the sum over j < i of ((h_results[j].comp_size + 15) & ~15) (entries whose
  * status is not OZG_ST_OK take no room) instead of at dst_off[i].  dst_off / dst_cap still describe the
  * device-side slots; h_dst needs room for the packed bytes only (at most dst_len).  What the batched
- * writer of zip_close uses: the worst-case slot layout is 2-3 x the bytes that matter. */
+ * writer of zip_close uses: the worst-case slot layout is 2-3 x the bytes that matter.  The payload's copy
+ * to the host can only be issued once the sizes are back: ozg_job_wait does that, and so does an ozg_job_done
+ * poll that finds them back (it then reports 0 until that copy has finished too). */
 int ozg_encode_submit_packed(const void *h_src, uint64_t src_len, void *h_dst, uint64_t dst_len,
 	const ozg_enc_entry *entries, ozg_enc_result *h_results, uint32_t n, ozg_job **job);
 

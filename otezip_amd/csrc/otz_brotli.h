@@ -849,6 +849,14 @@ OTZ_DEV void otz_brotli_run(const u8 *in, u32 n_in, u8 *out, u32 cap, u32 eflags
 		*route = 2u; // OTZ_ZS_ROUTE_DONE: the CRC pass follows
 	} else if (st == OZG_ST_INTERNAL && arena_bytes < OTZ_BR_ARENA) {
 		*route = OTZ_BR_ROUTE_AGAIN;
+	} else if (st == OZG_ST_SIZE && (eflags & OZG_EF_SIZE_IS_CAP)) {
+		// the codec seam: a stream that is valid so far and wants more room than the caller gave -- that is
+		// the verdict (Z_BUF_ERROR there), not a reason to ask the reference's container decoder
+		res->status = OZG_ST_SIZE;
+		res->total_out = 0;
+		res->crc32 = 0;
+		res->flags = 0;
+		*route = 2u;
 	} else {
 		*route = 1u; // OTZ_ZS_ROUTE_PRIVATE: the reference's container decoder has the last word
 	}

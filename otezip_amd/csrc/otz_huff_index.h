@@ -3,15 +3,15 @@
 // src/lib/deflate-dec.inc.c:610-817, block headers :122-253, stored blocks :269-319.)
 //
 // A Huffman stream can only be cut where a token starts, and that is only known once
-// everything before it has been decoded.  The wavefront breaks the chain the way the
-// workgroup kernel of otz_inflate.h does, but with segments long enough that the extra
-// work stays small and with nothing but wave-level operations:
+// everything before it has been decoded.  The wavefront breaks the chain by speculation, and
+// pays for the speculation ONCE PER LANE, not once per stretch of input:
 //
-//   * a round covers 64 x OTZ_K1_S bits of input; lane l owns the segment
-//     [s_l, s_l + OTZ_K1_S).  The bytes of every lane (plus a warm-up stretch before and a
-//     token's reach behind its segment) sit in a private LDS slot with an odd dword
-//     stride: one unaligned 8-byte LDS read per token fetches its bits, free of bank
-//     conflicts although all lanes sit at the same offset of their segments;
+//   * a span covers 64 segments of S bits -- up to OTZ_K1_SMAX bits each, i.e. a whole block
+//     of a typical stream -- and lane l owns the segment [s_l, s_l + S) from end to end;
+//   * a lane's bits pass through LDS a PIECE (OTZ_K1_P bits) at a time: every lane stages the
+//     next piece of its own segment (plus a token's reach behind it) into its column of a
+//     [row][lane] window, so the lanes of a wavefront read 64 different banks wherever each of
+//     them stands, and carries its position, byte and token counts from piece to piece;
 //   * walk A: every lane but lane 0 starts OTZ_K1_WARM bits BEFORE its segment at a
 //     guessed position.  A prefix code decoded from a wrong position falls into step with
 //     the real chain after a few tokens, so by s_l the lane is usually on it.  From s_l on
@@ -20,43 +20,34 @@
 //   * fixpoint: lane l's true start is where lane l-1 really ended (one v_mov_dpp).  If
 //     that is the first token walk A saw in the segment, the lane is confirmed; otherwise
 //     walk B re-decodes from the true start until it lands on one of walk A's checkpoints
-//     (or the segment ends).  A lane whose end moved makes its right neighbour repeat;
-//     with 512-bit segments that almost never cascades;
+//     (or the segment ends) -- usually within the segment's first piece.  A lane whose end
+//     moved makes its right neighbour repeat; that almost never cascades;
 //   * the first lane whose path ends the block, breaks, or runs out of input (or that
-//     exceeds its token budget) closes the round; the lanes before it are accepted: prefix
-//     sums give every item its output position and its slot in the block's item list.
+//     exceeds its token budget) closes the span; the lanes before it are accepted: prefix
+//     sums give every item its output position and its slot in the block's item list.  The
+//     lanes behind a block's end walked the next block with the wrong code: a span is cut to
+//     what the previous block took, so that they stay few.
 //
 // Nothing here waits on another wavefront: the kernel is launched with one 64-lane
-// workgroup per entry and the chip keeps ~13 of them per CU in flight.
+// workgroup per entry and the chip keeps twenty of them per CU in flight.
 #pragma once
 
 #include "otz_inflate.h"
 #include "otz_index.h"
 
-#ifndef OTZ_K1_S
-#define OTZ_K1_S 512u     // segment bits per lane per round (256 was measured: see DESIGN.md section 7)
+#ifndef OTZ_K1_P
+#define OTZ_K1_P 512u     // bits of its segment a lane stages per piece
 #endif
-#ifndef OTZ_K1_WARM
 #define OTZ_K1_WARM 128u  // head start of walk A (bits)
-#endif
-#define OTZ_K1_SEGW (OTZ_K1_S / 32u)                    // words of a lane's segment: 16 or 8
-#define OTZ_K1_SEGSH (OTZ_K1_S == 512u ? 4u : 3u)       // log2 of that
-#define OTZ_K1_SLOT (OTZ_K1_WARM / 8u + OTZ_K1_S / 8u + 12u) // bytes a lane may touch: WARM/8 before its segment + S/8 + 12 behind
-// The round's input sits in LDS ONCE, as one window: [segment of lane 0 - WARM/8 bytes, segment of lane 63
-// + 12 bytes).  A lane's warm-up stretch is its left neighbour's tail and its look-ahead its right
-// neighbour's head, so nothing is stored twice (private per-lane slots took 5.9 KB: with 4.4 KB here and
-// trimmed tables the wavefront fits 8 KB of LDS, i.e. five wavefronts per SIMD instead of four).
-// Lanes read at the same offset of their 16-word segments: one padding word after every 16 makes the
-// lane stride 17 words, which keeps those reads on different banks.
-#define OTZ_K1_WIN_BYTES (OTZ_K1_WARM / 8u + 64u * (OTZ_K1_S / 8u) + 16u) // 16 + 4096 (or 2048) + 16
-#define OTZ_K1_WIN_WORDS (OTZ_K1_WIN_BYTES / 4u)
-#define OTZ_K1_WIN_PADDED (OTZ_K1_WIN_WORDS + OTZ_K1_WIN_WORDS / OTZ_K1_SEGW + 2u)
-#define OTZ_K1_NCAP (OTZ_K1_ROWS * OTZ_IX_G) // tokens a walk may take per round
+#define OTZ_K1_PW (OTZ_K1_P / 32u)    // words of a piece
+#define OTZ_K1_WROWS (OTZ_K1_PW + 2u) // window rows (words per lane): the piece and the reach of a token that starts on its
+                                      // last bit (two words more).  With 512-bit pieces the wavefront's LDS is 7680 bytes: the
+                                      // CU hands LDS out in 1280-byte granules (measured: 7808 bytes admit 18 wavefronts, not 20),
+                                      // six of them is the most that leaves room for twenty wavefronts
 #define OTZ_K1_HDR_WORDS 264u // staged bytes for a block header: 17 + 57 + 318 x 14 bits < 1056 bytes
 
-static_assert (OTZ_K1_S % 8u == 0 && OTZ_K1_WARM % 8u == 0, "byte-granular slots");
-static_assert ((OTZ_K1_S == 512u || OTZ_K1_S == 256u) && OTZ_K1_WARM == 128u, "a lane's segment is 16 or 8 words, its slot starts 4 words before it");
-static_assert (OTZ_K1_SLOT >= OTZ_K1_WARM / 8u + OTZ_K1_S / 8u + 9u, "a token starting on the segment's last bit must fit");
+static_assert (OTZ_K1_P % 128u == 0 && OTZ_K1_P >= 256u && OTZ_K1_WARM == 128u, "a piece is a whole number of 16-byte loads; the warm-up and the early token starts lie in the first piece");
+static_assert (OTZ_K1_SMIN % 32u == 0 && OTZ_K1_SMAX % 32u == 0 && OTZ_K1_WARM + 7u + OTZ_K1_SMAX + 48u < (1u << 24), "segments are whole words; positions fit the exit word");
 static_assert ((OTZ_IX_G & (OTZ_IX_G - 1u)) == 0, "power of two");
 
 #define OTZ_K1_NONE 0xFFFFFFFFu
@@ -90,7 +81,7 @@ static_assert ((OTZ_IX_G & (OTZ_IX_G - 1u)) == 0, "power of two");
 // compressors write stay far below these sizes, and a block that does not fit sends its entry to the
 // self-contained kernel (OTZ_IX_OVERFLOW), so the sizes are a speed choice, never a correctness one.
 #ifndef OTZ_K1_LLUT
-#define OTZ_K1_LLUT 1216u // 1024 + 192
+#define OTZ_K1_LLUT 1152u // 1024 + 128
 #endif
 #ifndef OTZ_K1_DLUT
 #define OTZ_K1_DLUT 384u  // 256 + 128
@@ -100,7 +91,7 @@ struct otz_k1_lds {
 	u16 lit[OTZ_K1_LLUT];
 	u16 dist[OTZ_K1_DLUT];
 	union {
-		u32 win[OTZ_K1_WIN_PADDED];
+		u32 win[OTZ_K1_WROWS * 64u]; // [row][lane]: the piece every lane has staged
 		struct { // block prologue only
 			u32 hdr_w[OTZ_K1_HDR_WORDS + 4u];
 			u32 cl_lut[128];
@@ -110,6 +101,7 @@ struct otz_k1_lds {
 		} h;
 	};
 };
+static_assert (OTZ_K1_P != 512u || sizeof (otz_k1_lds) <= 6u * 1280u, "twenty wavefronts per CU: six 1280-byte granules of LDS each");
 
 // ------------------------------------------------------------------ wave helpers
 
@@ -173,7 +165,7 @@ OTZ_DEV otz_hdr otz_k1_parse_header(otz_k1_lds &L, u32 p, u64 avail, u32 *cl_ok)
 		H.st = OZG_ST_DATA;
 		return H;
 	}
-	const u32 lane = otz_lane ();
+	const u32 lane = otz_opaque (otz_lane ()); // (opaque: nothing derived from it is computed once at the top of the kernel and kept, spilled, across everything else)
 	L.h.cl_lut[lane] = 0;
 	L.h.cl_lut[lane + 64u] = 0;
 	otz_wave_sync ();
@@ -218,7 +210,7 @@ OTZ_DEV otz_hdr otz_k1_parse_header(otz_k1_lds &L, u32 p, u64 avail, u32 *cl_ok)
 // ("repeat the previous length") without a serial pass.
 // Returns 0 and the bits consumed, or OZG_ST_DATA.
 OTZ_DEV int otz_k1_parse_lengths(otz_k1_lds &L, u32 p, u64 avail, u32 n, u32 *bits_used) {
-	const u32 lane = otz_lane ();
+	const u32 lane = otz_opaque (otz_lane ());
 	for (u32 i = lane; i < OTZ_IX_LENS; i += 64u) {
 		L.h.ll[i] = 0;
 	}
@@ -326,7 +318,7 @@ OTZ_DEV u32 otz_k1_mk_dist(u32 sym, u32 len) {
 // Returns 0, OZG_ST_DATA for an over-subscribed set, or OTZ_IX_OVERFLOW when the sub-tables
 // do not fit these (smaller) tables.
 OTZ_DEV int otz_k1_build_tables(otz_k1_lds &L, u32 hlit, u32 hdist) {
-	const u32 lane = otz_lane ();
+	const u32 lane = otz_opaque (otz_lane ());
 	const u64 below = ((u64)1 << lane) - 1u;
 	for (u32 i = lane; i < OTZ_K1_LLUT / 2u; i += 64u) {
 		reinterpret_cast<u32 *> (L.lit)[i] = OTZ_K1_SPECIAL * 0x10001u; // no code
@@ -462,17 +454,6 @@ OTZ_DEV int otz_k1_build_tables(otz_k1_lds &L, u32 hlit, u32 hdist) {
 
 // ------------------------------------------------------------------ the walks
 
-struct otz_k1_path {
-	u32 exit;   // OTZ_X_MAKE (kind, slot-relative bit position): next token start, or the position after an EOB code
-	u32 n;      // tokens taken (each produced output)
-	u32 bytes;  // their output bytes
-	u32 first;  // walk A: first token start at or behind the segment start (OTZ_K1_NONE: none)
-	u32 tstart; // where the walk stopped: start of the token it could not take (the EOB code when it ended on one)
-	u64 bm;     // walk A: bit (u - s) set for every token start u < s + 64
-	u32 mpos;   // walk B: position where it landed on walk A's path (OTZ_K1_NONE: never)
-	u32 mrow;   // walk B: ... which is walk A's checkpoint row mrow, or OTZ_K1_NONE when it is one of the early token starts
-};
-
 struct otz_k1_tok {
 	u32 nbits;  // stream bits of the whole token
 	u32 obytes; // output bytes: 1 for a literal, the match length
@@ -507,55 +488,52 @@ OTZ_DEV otz_k1_tok otz_k1_decode_bits(const otz_k1_lds &L, u32 lo, u32 hi) {
 	return t;
 }
 
-// The three window words from the one that holds slot-relative bit u of the lane whose slot starts at
-// window word `slot` (= OTZ_K1_SEGW x lane): dword-aligned reads and a funnel shift (a byte-unaligned 8-byte LDS
-// read costs 5x the LDS time); word i of the window lives at win[i + i / 16].
-OTZ_DEV void otz_k1_words(const otz_k1_lds &L, u32 slot, u32 u, u32 &w0, u32 &w1, u32 &w2) {
-	const u32 i0 = slot + otz_opaque (u >> 5), i1 = i0 + 1u, i2 = i0 + 2u;
-	w0 = L.win[i0 + (i0 >> OTZ_K1_SEGSH)];
-	w1 = L.win[i1 + (i1 >> OTZ_K1_SEGSH)];
-	w2 = L.win[i2 + (i2 >> OTZ_K1_SEGSH)];
+// The three window words from the one that holds slot-relative bit u.  The window is [row][lane]: word r
+// of the piece a lane has staged lives at win[64 r + lane], so the lanes of a wavefront hit 64 different
+// banks wherever each of them stands, and the three words are one address and two constant offsets.
+// lb = 4 * lane - 256 * (first word of the piece), modulo 2^32.
+OTZ_DEV void otz_k1_words(const otz_k1_lds &L, u32 lb, u32 u, u32 &w0, u32 &w1, u32 &w2) {
+	const u32 a = (otz_opaque (u >> 5) << 8) + lb;
+	const u32 *p = reinterpret_cast<const u32 *> (reinterpret_cast<const u8 *> (L.win) + a);
+	w0 = p[0];
+	w1 = p[64];
+	w2 = p[128];
 }
-OTZ_DEV otz_k1_tok otz_k1_decode(const otz_k1_lds &L, u32 slot, u32 u) {
+OTZ_DEV otz_k1_tok otz_k1_decode(const otz_k1_lds &L, u32 lb, u32 u) {
 	u32 w0, w1, w2;
-	otz_k1_words (L, slot, u, w0, w1, w2);
+	otz_k1_words (L, lb, u, w0, w1, w2);
 	return otz_k1_decode_bits (L, otz_alignbit (w1, w0, u), otz_alignbit (w2, w1, u));
 }
 
-// The step of the walks' loops.  Both kernels of the DEFLATE decode are bound by VALU issue (a
-// wave64 VALU instruction holds its SIMD for four cycles; scalar instructions issue beside it), so
-// this is written to the instruction: ~27 VALU instructions per token --
-//   3 window words (7: addresses) + 2 funnel shifts, literal/length lookup (2: address), 3 field
-//   extractions, the special test, funnel shift + distance lookup (3), B, "a distance follows"
-//   + select (2), the token's bits and bytes (3 three-operand adds / bit-field extracts).
-// Lanes leave the loops through the execution mask (scalar instructions), nothing is selected
-// per lane.  stop: no token can be taken here (end of block, reserved symbol, no such code).
+// The step of the walks' loops: window words (2 VALU for the address), 2 funnel shifts, literal/length
+// lookup, field extractions, funnel shift + distance lookup, the token's bits and bytes.  Straight-line but
+// for the rare second-level lookups: the distance entry is fetched for every lane (a literal reads some
+// entry and ignores it) -- a branch around it would cost more than the lookup and every step has both kinds.
+// stop: no token can be taken here (end of block, reserved symbol, no such code).
 struct otz_k1_step {
 	u32 nb;   // bits of the token; beyond every limit when its distance code is reserved
 	u32 ob;   // bytes it yields
 	bool stop;
 };
-OTZ_DEV otz_k1_step otz_k1_hot(const otz_k1_lds &L, u32 slot, u32 u) {
+OTZ_DEV otz_k1_step otz_k1_hot(const otz_k1_lds &L, u32 lb, u32 u) {
 	u32 w0, w1, w2;
-	otz_k1_words (L, slot, u, w0, w1, w2);
+	otz_k1_words (L, lb, u, w0, w1, w2);
 	const u32 lo = otz_alignbit (w1, w0, u), hi = otz_alignbit (w2, w1, u);
 	u32 e = L.lit[lo & ((1u << OTZ_K1_LROOT) - 1u)];
 	u32 xb = otz_bfe (e, 4, 3);
-	otz_k1_step r;
-	r.stop = false;
-	if (xb == 7u) { // rare: a code longer than the root, or the end of the block
-		if ((e >> 7) >= 3u) {
-			e = L.lit[(1u << OTZ_K1_LROOT) + 2u * ((e >> 7) - 3u) + otz_bfe (lo, OTZ_K1_LROOT, e & 15u)];
-			xb = otz_bfe (e, 4, 3);
-		}
-		r.stop = xb == 7u;
+	if (xb == 7u && (e >> 7) >= 3u) { // rare: a code longer than the root
+		e = L.lit[(1u << OTZ_K1_LROOT) + 2u * ((e >> 7) - 3u) + otz_bfe (lo, OTZ_K1_LROOT, e & 15u)];
+		xb = otz_bfe (e, 4, 3);
 	}
+	otz_k1_step r;
+	r.stop = xb == 7u;
 	const u32 len = e & 15u, used = len + xb;
 	const u32 db = otz_alignbit (hi, lo, used);
-	u32 d = L.dist[db & ((1u << OTZ_K1_DROOT) - 1u)]; // (a literal reads some entry and ignores it)
+	u32 d = L.dist[db & ((1u << OTZ_K1_DROOT) - 1u)];
+	otz_touch32 (d); // (fetched here, for every lane)
 	const u32 B = e >> 7;
 	const bool is_len = B > 2u;
-	if (is_len && (d & 0x8000u) != 0) {
+	if (is_len && (d & 0x8000u) != 0) { // rare: a distance code longer than the root
 		d = L.dist[(1u << OTZ_K1_DROOT) + ((d >> 4) & 0x7FFu) + otz_bfe (db, OTZ_K1_DROOT, d & 15u)];
 	}
 	r.nb = used + (is_len ? d : 0u);
@@ -563,15 +541,9 @@ OTZ_DEV otz_k1_step otz_k1_hot(const otz_k1_lds &L, u32 slot, u32 u) {
 	return r;
 }
 
-// How a walk that stopped at slot-relative bit u ends: the exit word.
-OTZ_DEV u32 otz_k1_classify(const otz_k1_lds &L, u32 slot, u32 u, u32 e, u32 limit, bool capped) {
-	if (capped) {
-		return OTZ_X_MAKE (OTZ_X_CAP, u); // token budget used up
-	}
-	if (u >= e) {
-		return OTZ_X_MAKE (OTZ_X_NORMAL, u);
-	}
-	const otz_k1_tok t = otz_k1_decode (L, slot, u); // the token it stopped at
+// How a walk that stopped at slot-relative bit u (in front of e, inside the staged piece) ends: the exit word.
+OTZ_DEV u32 otz_k1_classify(const otz_k1_lds &L, u32 lb, u32 u, u32 limit) {
+	const otz_k1_tok t = otz_k1_decode (L, lb, u); // the token it stopped at
 	if (u >= limit) {
 		return OTZ_X_MAKE (OTZ_X_TRUNC_END, u);
 	}
@@ -584,129 +556,234 @@ OTZ_DEV u32 otz_k1_classify(const otz_k1_lds &L, u32 slot, u32 u, u32 e, u32 lim
 	return OTZ_X_MAKE (OTZ_X_EOB, u + t.nbits); // (kind 1: a token that neither breaks nor ends the input is taken)
 }
 
-// The walks.  All 64 lanes call; `run` selects the lanes that walk.
-//   SPEC (walk A): from `start`, OTZ_K1_WARM bits ahead of the segment: first a warm-up loop
-//     (tokens neither counted nor noted) up to the first token start at or behind s, then
-//     the main loop.  It notes a checkpoint (position, bytes so far) every OTZ_IX_G tokens in
-//     its column of `rows`, and the token starts of the segment's first 64 bits in a bitmap.
-//   !SPEC (walk B): from the lane's true start; stops as soon as it stands on walk A's path:
-//     on one of the early token starts (bmA) or on a checkpoint (rowsA / nckA).
-// rows / rowsA: [row][lane], the base is the same in every lane.
-// Every walking lane takes one token per iteration of the main loop, so the iteration number is
-// the token count: the checkpoint cadence is a scalar branch and a row of checkpoints is one
-// coalesced store.
-// state of a walk's main loop (registers; the loop is instantiated twice -- its first iterations
-// carry the bookkeeping of the early token starts, the steady state does not)
+// Checkpoint (row r, this lane) of a walk's rows, [row][lane], 512 bytes a row.  The address is the rows' base (the
+// same in every lane: scalar registers) plus a 32-bit byte offset -- no 64-bit per-lane index arithmetic.
+OTZ_DEV const otz_ix_item *otz_k1_row(const otz_ix_item *rows, u32 r, u32 lane8) {
+	return reinterpret_cast<const otz_ix_item *> (reinterpret_cast<const u8 *> (rows) + ((r << 9) + lane8));
+}
+
+// State of a walk (registers), carried from piece to piece of the lane's segment.
 struct otz_k1_ws {
-	u32 u, bytes, cnt;
-	u64 bm;
-	bool merged, capped;
-	u32 c, cpos;
-	otz_ix_item *row; // this lane's place in the next checkpoint row
+	u32 u;       // slot-relative bit position: start of the next token
+	u32 bytes;   // output bytes of the tokens taken
+	u32 cnt;     // tokens taken (each produced output)
+	bool alive;  // still walking
+	bool halted; // stopped in front of a token it cannot take (classified while the piece is staged)
+	bool merged; // walk B: landed on walk A's path
+	bool capped; // token budget used up
+	u64 bm;      // walk A: bit (u - s) set for every token start u < s + 64
+	u32 first;   // walk A: where its chain starts (the first token start at or behind s, or where it started over)
+	u32 c, cpos; // walk B: walk A's next checkpoint at or behind u
+	u32 exit;    // exit word once the walk has ended
 };
 
-// iterations [n0, n1) for the lanes that are still walking (the caller's execution mask); returns
-// false for a lane that has stopped
+// One piece of a walk: the lanes with W.alive take tokens while they stand in front of `pend`.
+//   SPEC (walk A): notes a checkpoint (position, bytes so far) before every OTZ_IX_G-th token of the lane, in its
+//     column of `rows` ([row][lane]), and -- EARLY -- the token starts of the segment's first 64 bits in a bitmap.
+//   !SPEC (walk B): the same checkpoints in its own rows; stops as soon as it stands on walk A's path: on one of
+//     the early token starts (bmA, EARLY) or on a checkpoint (rowsA / nckA).
+// ncap: token budget (a multiple of OTZ_IX_G).
+// The loop has ONE exit test and no branch in its body but for the rare paths: a lane that has to stop does so by
+// raising a bit above every position in its own u (a break out of the middle of the body costs a dozen scalar
+// instructions of execution-mask bookkeeping per way out, every iteration), and a step that must not count is
+// computed and then not added.
+#define OTZ_K1_HALT 0x80000000u
+#define OTZ_K1_MERGE 0x40000000u
+#define OTZ_K1_RESTART 64u // tokens: a guessed chain that stops before it has come this far starts over
 template <bool SPEC, bool EARLY>
-OTZ_DEV bool otz_k1_walk_span(const otz_k1_lds &L, u32 slot, otz_k1_ws &W, u32 n0, u32 n1, u32 s, u32 e, u32 lim2, const otz_ix_item *rowsA, u64 bmA, u32 nckA) {
-	const u32 lane = otz_lane ();
-	for (u32 n = n0; n < n1; n++) {
+OTZ_DEV void otz_k1_walk_loop(const otz_k1_lds &L, u32 lb, otz_k1_ws &W, u32 pend, u32 s, u32 lim2, u32 ncap, otz_ix_item *rows,
+	const otz_ix_item *rowsA, u64 bmA, u32 nckA) {
+	const u32 lane8 = 8u * otz_opaque (otz_lane ());
+	u32 u = W.alive ? W.u : OTZ_K1_HALT;
+	u32 bytes = W.bytes, cnt = W.cnt, first = W.first;
+	u64 bm = W.bm;
+	// Walk A is a guess until it has met the real chain, and a guessed chain runs into an end-of-block code (or
+	// a reserved one) once in a few thousand tokens -- in one span out of four some lane does.  With segments
+	// this long that lane must not give up (its whole segment would be walked again, alone): it starts over
+	// one bit further on, as a new chain -- first token, counts, checkpoints and all.  Only early on: a chain
+	// that has come OTZ_K1_RESTART tokens far has met the real one, and what stops it then stops the block.
+	// (Whatever walk A does is a hint: the true path is walk B's, up to where it lands on walk A's chain.)
+	const bool may_restart = SPEC && otz_lane () != 0;
+	while (u < pend && cnt < ncap) {
+		bool hit = false;
 		if (!SPEC) {
-			while (W.cpos < W.u) { // (rare: passed a checkpoint of walk A without landing on it)
+			while (W.cpos < u) { // (rare: passed a checkpoint of walk A without landing on it)
 				W.c++;
-				W.cpos = W.c < nckA ? rowsA[W.c * 64u + otz_opaque (lane)].bit : OTZ_K1_NONE;
+				W.cpos = W.c < nckA ? otz_k1_row (rowsA, W.c, lane8)->bit : OTZ_K1_NONE;
 			}
-			bool hit = W.cpos == W.u;
+			hit = W.cpos == u;
 			if (EARLY) { // the early token starts of walk A
-				const u32 rel = W.u - s;
+				const u32 rel = u - s;
 				hit = hit || (rel < 64u && ((bmA >> rel) & 1u) != 0);
-			}
-			if (hit) {
-				W.merged = true;
-				W.capped = false;
-				return false;
 			}
 		}
 		if (SPEC && EARLY) {
-			const u32 rel = W.u - s;
-			if (rel < 64u) {
-				W.bm |= (u64)1 << rel;
-			}
+			const u32 rel = u - s;
+			bm |= rel < 64u ? (u64)1 << rel : 0u;
 		}
-		if ((n & (OTZ_IX_G - 1u)) == 0) {
+		if ((cnt & (OTZ_IX_G - 1u)) == 0) {
 			otz_ix_item k;
-			k.bit = W.u;
-			k.out = W.bytes;
-			*W.row = k;
-			W.row += 64u; // (here, not per iteration: the address arithmetic is VALU work too)
+			k.bit = u;
+			k.out = bytes;
+			// (row cnt / G, 512 bytes a row: cnt is a multiple of G here)
+			*reinterpret_cast<otz_ix_item *> (reinterpret_cast<u8 *> (rows) + ((cnt << 6) + lane8)) = k;
 		}
-		const otz_k1_step h = otz_k1_hot (L, slot, W.u);
-		const u32 tend = W.u + h.nb;
-		if (h.stop || tend > lim2) {
-			W.capped = false;
-			return false;
-		}
-		W.u = tend;
-		W.bytes += h.ob;
-		W.cnt = n + 1u;
-		if (tend >= e) {
-			W.capped = false;
-			return false;
+		const otz_k1_step h = otz_k1_hot (L, lb, u);
+		const u32 tend = u + h.nb;
+		const bool bad = h.stop || tend > lim2;
+		const bool adv = !bad && !hit;
+		if (SPEC) {
+			const bool again = may_restart && h.stop && tend <= lim2 && cnt < OTZ_K1_RESTART;
+			bytes = again ? 0u : bytes + (adv ? h.ob : 0u);
+			cnt = again ? 0u : cnt + (adv ? 1u : 0u);
+			first = again ? u + 1u : first;
+			if (EARLY) {
+				bm = again ? 0u : bm;
+			}
+			u = again ? u + 1u : bad ? u | OTZ_K1_HALT : tend;
+		} else {
+			bytes += adv ? h.ob : 0u;
+			cnt += adv ? 1u : 0u;
+			u = hit ? u | OTZ_K1_MERGE : bad ? u | OTZ_K1_HALT : tend;
 		}
 	}
-	return true;
+	if (W.alive) {
+		W.bytes = bytes;
+		W.cnt = cnt;
+		W.bm = bm;
+		W.first = first;
+		W.u = u & ~(OTZ_K1_HALT | OTZ_K1_MERGE);
+		if (u & OTZ_K1_MERGE) {
+			W.merged = true;
+			W.alive = false;
+		} else if (u & OTZ_K1_HALT) {
+			W.halted = true;
+			W.alive = false;
+		} else if (u < pend) { // (cnt == ncap)
+			W.capped = true;
+			W.alive = false;
+		}
+	}
 }
 
+// Stage piece k of every lane's slot: OTZ_K1_WROWS words from entry byte slot0 + k * P / 8 (zeros outside the
+// entry), each lane its own column of the window.
+OTZ_DEV void otz_k1_stage_piece(otz_k1_lds &L, const u8 *in, u32 n_in, int64_t slot0, u32 k) {
+	const u32 lane = otz_lane ();
+	const int64_t b = slot0 + (int64_t) (k * (OTZ_K1_P / 8u));
+	static_assert (OTZ_K1_WROWS % 4u == 2u, "whole 16-byte loads and half of one");
+#pragma unroll
+	for (u32 q = 0; q < (OTZ_K1_WROWS + 3u) / 4u; q++) {
+		const otz_u4 v = otz_k1_ld16 (in, n_in, b + 16 * (int64_t)q);
+		u32 *d = &L.win[(4u * q) * 64u + lane];
+		d[0] = v.x;
+		d[64] = v.y;
+		if (4u * q + 2u < OTZ_K1_WROWS) {
+			d[128] = v.z;
+			d[192] = v.w;
+		}
+	}
+}
+
+// A whole walk over the lanes' segments [s, e) of the span, piece by piece.  All 64 lanes call.
+//   SPEC (walk A): every lane; lane 0 from s (the span's true start), the others from OTZ_K1_WARM bits ahead of
+//     their segment at a guessed position: a warm-up (tokens neither counted nor noted) up to the first token
+//     start at or behind s -- *first (OTZ_K1_NONE: none) -- then the walk proper.
+//   !SPEC (walk B): the lanes with `run`, from their true start `start` (inside the first piece); a lane that
+//     lands on one of walk A's early token starts also recounts walk A's tokens up to there (*jm tokens,
+//     *offA bytes; firstA: walk A's first token) while that piece is still staged.
+// Ends with every lane's W.exit set.
 template <bool SPEC>
-OTZ_DEV otz_k1_path otz_k1_walk(const otz_k1_lds &L, u32 slot, bool run, u32 start, u32 s, u32 e, u32 limit,
-	otz_ix_item *rows, const otz_ix_item *rowsA, u64 bmA, u32 nckA) {
+OTZ_DEV void otz_k1_walk(otz_k1_lds &L, const u8 *in, u32 n_in, int64_t slot0, otz_k1_ws &W, bool run, u32 start, u32 s, u32 e, u32 limit,
+	u32 ncap, otz_ix_item *rows, const otz_ix_item *rowsA, u64 bmA, u32 nckA, u32 firstA, u32 *first, u32 *jm, u32 *offA) {
 	const u32 lane = otz_lane ();
 	// a token that starts in front of e ends in front of e + 48: the clamp changes nothing for
 	// tokens that exist and puts a reserved distance code (OTZ_K1_DBAD bits) beyond the limit
 	const u32 lim2 = limit < e + 48u ? limit : e + 48u;
-	otz_k1_path P;
-	otz_k1_ws W;
 	W.u = run ? start : s;
-	bool alive = run;
-	if (SPEC) {
-		if (alive) {
-			while (W.u < s) {
-				const otz_k1_step h = otz_k1_hot (L, slot, W.u);
-				const u32 tend = W.u + h.nb;
-				if (h.stop || tend > lim2) {
-					alive = false;
-					break;
+	W.bytes = W.cnt = 0;
+	W.alive = run;
+	W.halted = W.merged = W.capped = false;
+	W.bm = 0;
+	W.first = OTZ_K1_NONE;
+	W.c = 1; // walk B: walk A's next checkpoint at or behind u (row 0 is its first token: bmA has it)
+	W.cpos = OTZ_K1_NONE;
+	W.exit = OTZ_X_MAKE (OTZ_X_INVALID, W.u);
+	if (!SPEC) {
+		W.cpos = run && nckA > 1u ? otz_k1_row (rowsA, 1u, 8u * otz_opaque (lane))->bit : OTZ_K1_NONE;
+	}
+	const u32 npieces = (e + OTZ_K1_P - 1u) / OTZ_K1_P;
+	for (u32 k = 0; k < npieces; k++) {
+		const u32 pend = (k + 1u) * OTZ_K1_P < e ? (k + 1u) * OTZ_K1_P : e;
+		if (!SPEC) {
+			if (otz_ballot (W.alive) == 0) {
+				break;
+			}
+			if (otz_ballot (W.alive && W.u < pend) == 0) {
+				continue; // (no lane stands in this piece)
+			}
+		}
+		const u32 lb = 4u * lane - 256u * OTZ_K1_PW * k;
+		// (LDS only, and the LDS executes a wavefront's instructions in order: nothing has to drain -- in particular
+		// not the checkpoint stores, which stay in flight across pieces)
+		otz_wave_sync_lds (); // the previous piece (or the block prologue's scratch) is dead
+		otz_k1_stage_piece (L, in, n_in, slot0, k);
+		otz_wave_sync_lds ();
+		if (SPEC && k == 0) {
+			// the warm-up: nothing is counted or noted, and a guess that runs into a code it cannot take moves on a bit
+			u32 u = W.u;
+			while (u < s) {
+				const otz_k1_step h = otz_k1_hot (L, lb, u);
+				const u32 tend = u + h.nb;
+				u = tend > lim2 ? u | OTZ_K1_HALT : h.stop ? u + 1u : tend;
+			}
+			W.alive = (u & OTZ_K1_HALT) == 0;
+			W.u = u & ~OTZ_K1_HALT;
+			W.first = W.alive ? W.u : OTZ_K1_NONE;
+			W.exit = OTZ_X_MAKE (OTZ_X_INVALID, W.u);
+		}
+		if (k == 0) {
+			const u32 pe = s + 64u < pend ? s + 64u : pend;
+			otz_k1_walk_loop<SPEC, true> (L, lb, W, pe, s, lim2, ncap, rows, rowsA, bmA, nckA);
+		}
+		otz_k1_walk_loop<SPEC, false> (L, lb, W, pend, s, lim2, ncap, rows, rowsA, bmA, nckA);
+		// the lanes that stopped in this piece: how their walk ends
+		if (otz_ballot (W.halted) != 0) {
+			if (W.halted) {
+				W.exit = otz_k1_classify (L, lb, W.u, limit);
+				W.halted = false;
+			}
+		}
+		if (!SPEC && k == 0) {
+			// landed on one of walk A's early token starts: count walk A's tokens up to there
+			const bool early = W.merged && W.cpos != W.u;
+			if (otz_ballot (early) != 0) {
+				u32 x = firstA, j = 0, ob = 0;
+				while (early && x < W.u) {
+					const otz_k1_tok tk = otz_k1_decode (L, lb, x);
+					x += tk.nbits;
+					ob += tk.obytes;
+					j++;
 				}
-				W.u = tend;
+				if (early) {
+					*jm = j;
+					*offA = ob;
+				}
 			}
 		}
 	}
-	const u32 first = alive ? W.u : OTZ_K1_NONE;
-	W.cnt = W.bytes = 0;
-	W.bm = 0;
-	W.merged = W.capped = false;
-	W.c = 1; // walk B: walk A's next checkpoint at or behind u (row 0 is its first token: bmA has it)
-	W.cpos = OTZ_K1_NONE;
-	W.row = rows + otz_opaque (lane); // (opaque: a per-lane 64-bit pointer kept alive across the whole entry is a spilled register pair)
-	if (!SPEC) {
-		W.cpos = run && nckA > 1u ? rowsA[64u + otz_opaque (lane)].bit : OTZ_K1_NONE;
-	}
-	if (alive) {
-		W.capped = true;
-		constexpr u32 NE = SPEC ? 8u : 16u;
-		if (otz_k1_walk_span<SPEC, true> (L, slot, W, 0, NE, s, e, lim2, rowsA, bmA, nckA)) {
-			(void)otz_k1_walk_span<SPEC, false> (L, slot, W, NE, OTZ_K1_NCAP, s, e, lim2, rowsA, bmA, nckA);
+	if (SPEC) {
+		*first = W.first;
+		if (W.first >= s + 64u) {
+			W.bm = 0; // (a chain that started over behind the early stretch: the bits are its predecessor's)
 		}
 	}
-	P.exit = alive && !W.merged ? otz_k1_classify (L, slot, W.u, e, limit, W.capped) : OTZ_X_MAKE (OTZ_X_INVALID, W.u);
-	P.n = W.cnt;
-	P.bytes = W.bytes;
-	P.first = first;
-	P.tstart = W.u;
-	P.bm = W.bm;
-	P.mpos = W.merged ? W.u : OTZ_K1_NONE;
-	P.mrow = W.merged && W.cpos == W.u ? W.c : OTZ_K1_NONE;
-	return P;
+	if (W.alive) {
+		W.exit = OTZ_X_MAKE (OTZ_X_NORMAL, W.u); // ran through its segment: the next token starts at u >= e
+	} else if (W.capped) {
+		W.exit = OTZ_X_MAKE (OTZ_X_CAP, W.u); // token budget used up (not an error; the block goes on)
+	}
+	otz_wave_sync (); // the checkpoint rows are read by other lanes from here on
 }
 
 // ------------------------------------------------------------------ the entry
@@ -717,8 +794,8 @@ OTZ_DEV otz_k1_path otz_k1_walk(const otz_k1_lds &L, u32 slot, bool run, u32 sta
 // entry's output address is 16-byte aligned; region/region_bytes: the entry's arena region
 // (region_bytes = 0: none could be carved).  head: the entry's index head.
 // Returns true when the index did not fit (head->status = OTZ_IX_OVERFLOW).
-// prof: optional 16 x u64 diagnostic cycle counters (0 header+lengths, 1 tables, 2 slot load, 3 walk A,
-// 4 fixpoint, 5 accept+items, 6 rounds, 7 fixpoint iterations, 8 re-walks, 9 blocks, 15 total)
+// prof: optional 16 x u64 diagnostic cycle counters (0 header+lengths, 1 tables, 3 walk A,
+// 4 fixpoint, 5 accept+items, 6 spans, 7 fixpoint iterations, 8 re-walks, 9 blocks, 15 total)
 // (PROF is a compile-time switch: the counters would otherwise occupy two dozen scalar registers
 // of the product kernel)
 #define OTZ_K1_MARK(i) \
@@ -751,26 +828,31 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 	u64 eob_abs = 0, clip_abs = 0;
 	bool last_block = false, ended = false;
 	u32 prev_next_at = 0; // region offset of the previous block's `next` field (0: none)
+	// how much input a span covers at most: what the previous block took (compressors cut blocks of similar
+	// size), so that the lanes behind the block's end -- which walk the next block with the wrong code -- stay few
+	u64 span_cap = 64ull * OTZ_K1_SMAX;
 
+	const u32 rowsA_cap = otz_k1_rows_a (n_in), rowsB_cap = otz_k1_rows_b (n_in);
+	const u32 temp_bytes = (rowsA_cap + rowsB_cap) * 512u;
 	if (!out_aligned) {
 		status = OZG_ST_INTERNAL;
 	} else if (n_in == 0) {
 		// ref: the loop at :610 never runs; Z_OK when there is no output space, else Z_BUF_ERROR
 		status = out_cap == 0 ? OTZ_K1_ST_NEED_OUT : OZG_ST_BUF;
-	} else if (region_bytes < OTZ_K1_TEMP_BYTES + 1024u) {
+	} else if (region_bytes < temp_bytes + 1024u) {
 		status = OTZ_IX_OVERFLOW;
 	}
-	const u32 rec_limit = region_bytes >= OTZ_K1_TEMP_BYTES + 1024u ? region_bytes - OTZ_K1_TEMP_BYTES : 0u;
+	const u32 rec_limit = region_bytes >= temp_bytes + 1024u ? region_bytes - temp_bytes : 0u;
 	// checkpoint rows of the two walks, [row][lane]
 	otz_ix_item *const rowsA = reinterpret_cast<otz_ix_item *> (region + rec_limit); // (the same in every lane)
-	otz_ix_item *const rowsB = rowsA + OTZ_K1_ROWS * 64u;
+	otz_ix_item *const rowsB = rowsA + rowsA_cap * 64u;
 
 	while (status == 0 && !ended) {
 		// ---- block header: stage the bytes behind the current position
 		const u32 hb = (u32) (abs_bit >> 3);
 		{
 			const otz_u4 v = otz_k1_ld16 (in, n_in, (int64_t)hb + 16 * (int64_t)lane);
-			otz_wave_sync (); // the slots of the previous round are dead from here
+			otz_wave_sync (); // the window of the previous span is dead from here
 			u32 *d = &L.h.hdr_w[4u * lane];
 			d[0] = v.x;
 			d[1] = v.y;
@@ -845,7 +927,7 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 		// ---- Huffman block: code lengths, tables
 		u32 hlit = 288, hdist = 32;
 		if (H.btype == 1) {
-			for (u32 i = lane; i < OTZ_IX_LENS; i += 64u) {
+			for (u32 i = otz_opaque (lane); i < OTZ_IX_LENS; i += 64u) { // (opaque: see otz_k1_parse_header)
 				L.h.ll[i] = (u8) (i <= 143u ? 8 : i <= 255u ? 9 : i <= 279u ? 7 : i <= 287u ? 8 : 5);
 			}
 			otz_wave_sync ();
@@ -864,7 +946,7 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 			status = OTZ_IX_OVERFLOW;
 			break;
 		}
-		for (u32 i = lane; i < OTZ_IX_LENS / 4u; i += 64u) { // the apply kernel rebuilds the tables from these
+		for (u32 i = otz_opaque (lane); i < OTZ_IX_LENS / 4u; i += 64u) { // the apply kernel rebuilds the tables from these
 			u32 w = 0;
 			for (u32 k = 0; k < 4u; k++) {
 				const u32 j = 4u * i + k;
@@ -889,33 +971,22 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 		u32 end_bit = 0; // block-relative position that closes the item list
 		bool block_done = false, serial_finish = false;
 
-		// ---- rounds
+		// ---- spans: 64 segments of S bits, one per lane
 		while (!block_done && status == 0) {
 			const u32 rb = (u32) (abs_bit >> 3), phi = (u32) (abs_bit & 7u);
-			const int64_t slot0 = (int64_t)rb + (int64_t) (OTZ_K1_S / 8u) * (int64_t)lane - (int64_t) (OTZ_K1_WARM / 8u); // entry byte of the slot's byte 0
-			const u32 slot = OTZ_K1_SEGW * lane; // window word of this lane's slot byte 0
-			otz_wave_sync (); // prologue scratch / previous round's window are dead
-			{
-				const int64_t win0 = (int64_t)rb - (int64_t) (OTZ_K1_WARM / 8u); // entry byte of window byte 0
-				for (u32 c = lane; c < OTZ_K1_WIN_BYTES / 16u; c += 64u) { // coalesced 16-byte loads, 4 words each
-					const otz_u4 v = otz_k1_ld16 (in, n_in, win0 + 16 * (int64_t)c);
-					u32 *d = &L.win[4u * c + (c >> (OTZ_K1_SEGSH - 2u))]; // (4c .. 4c+3 lie inside one segment-sized group: one padding offset)
-					d[0] = v.x;
-					d[1] = v.y;
-					d[2] = v.z;
-					d[3] = v.w;
-				}
-			}
-			otz_wave_sync ();
+			const u64 left = total_bits - 8ull * rb;
+			const u32 S = otz_k1_seg_bits (left < span_cap ? left : span_cap);
+			const int64_t slot0 = (int64_t)rb + (int64_t) (S / 8u) * (int64_t)lane - (int64_t) (OTZ_K1_WARM / 8u); // entry byte of the slot's byte 0
 			// slot-relative bit coordinates: the lane's segment is [s, e)
-			const u32 s = OTZ_K1_WARM + phi, e = s + OTZ_K1_S;
+			const u32 s = OTZ_K1_WARM + phi, e = s + S;
 			const int64_t lb = (int64_t)total_bits - 8 * slot0; // the input ends at this slot-relative bit
 			const u32 limit = lb <= 0 ? 0u : lb > 0xFFFFFF ? 0xFFFFFFu : (u32)lb;
-			OTZ_K1_MARK (2);
 			OTZ_K1_COUNT (6);
 			// ---- walk A
-			const otz_k1_path A = otz_k1_walk<true> (L, slot, true, lane ? s - OTZ_K1_WARM : s, s, e, limit, rowsA, rowsA, 0, 0);
-			const u32 nckA = (A.n + OTZ_IX_G - 1u) / OTZ_IX_G; // checkpoint rows in front of tokens walk A took
+			otz_k1_ws A;
+			u32 firstA = OTZ_K1_NONE, dummy0 = 0, dummy1 = 0;
+			otz_k1_walk<true> (L, in, n_in, slot0, A, true, lane ? s - OTZ_K1_WARM : s, s, e, limit, rowsA_cap * OTZ_IX_G, rowsA, rowsA, 0, 0, 0, &firstA, &dummy0, &dummy1);
+			const u32 nckA = (A.cnt + OTZ_IX_G - 1u) / OTZ_IX_G; // checkpoint rows in front of tokens walk A took
 			OTZ_K1_MARK (3);
 			// ---- fixpoint over the true starts.  A lane's true path: nB tokens of its own walk B
 			// (none when it starts on walk A's first token), then -- if it lands on walk A's path at
@@ -923,45 +994,39 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 			u32 t = lane == 0 ? s : OTZ_K1_NONE;
 			u32 exit_cur = A.exit;
 			bool onA = true;
-			u32 mp = A.first, jm = 0, offA = 0; // (lane 0: walk A is the true path)
+			u32 mp = firstA, jm = 0, offA = 0; // (lane 0: walk A is the true path)
 			u32 nB = 0, bytesB = 0, tstartB = 0;
 #pragma unroll 1
 			for (u32 it = 0; it < 64u; it++) {
 				const u32 prev = otz_lane_up1 (exit_cur, exit_cur);
 				// the left neighbour's exit is slot-relative to ITS slot: one segment further left
-				const u32 nt = lane && OTZ_X_KIND (prev) == OTZ_X_NORMAL ? OTZ_X_POS (prev) - OTZ_K1_S : OTZ_K1_NONE;
+				const u32 nt = lane && OTZ_X_KIND (prev) == OTZ_X_NORMAL ? OTZ_X_POS (prev) - S : OTZ_K1_NONE;
 				const bool moved = lane != 0 && nt != t && nt != OTZ_K1_NONE;
 				t = lane ? nt : t;
-				const bool rewalk = moved && nt != A.first;
+				const bool rewalk = moved && nt != firstA;
 				const u32 old_exit = exit_cur;
 				OTZ_K1_COUNT (7);
 				if (otz_ballot (rewalk) != 0) {
 					OTZ_K1_COUNT (8);
-					const otz_k1_path W = otz_k1_walk<false> (L, slot, rewalk, nt, s, e, limit, rowsB, rowsA, A.bm, nckA);
-					// where on walk A's path did it land: count walk A's tokens up to there
-					const bool early = rewalk && W.mpos != OTZ_K1_NONE && W.mrow == OTZ_K1_NONE;
-					u32 x = A.first, j = 0, ob = 0;
-					while (early && x < W.mpos) {
-						const otz_k1_tok tk = otz_k1_decode (L, slot, x);
-						x += tk.nbits;
-						ob += tk.obytes;
-						j++;
-					}
+					otz_k1_ws W;
+					u32 unused = 0, j = 0, ob = 0;
+					otz_k1_walk<false> (L, in, n_in, slot0, W, rewalk, nt, s, e, limit, rowsB_cap * OTZ_IX_G, rowsB, rowsA, A.bm, nckA, firstA, &unused, &j, &ob);
 					if (rewalk) {
-						nB = W.n;
+						const bool early = W.merged && W.cpos != W.u;
+						nB = W.cnt;
 						bytesB = W.bytes;
-						tstartB = W.tstart;
-						onA = W.mpos != OTZ_K1_NONE;
-						mp = W.mpos;
-						jm = early ? j : W.mrow * OTZ_IX_G;
-						offA = early ? ob : onA ? rowsA[W.mrow * 64u + otz_opaque (lane)].out : 0u;
+						tstartB = W.u;
+						onA = W.merged;
+						mp = W.merged ? W.u : OTZ_K1_NONE;
+						jm = early ? j : W.c * OTZ_IX_G;
+						offA = early ? ob : onA ? otz_k1_row (rowsA, W.c, 8u * otz_opaque (lane))->out : 0u;
 						exit_cur = onA ? A.exit : W.exit;
 					}
 				}
 				if (moved && !rewalk) { // lands on walk A's first token: confirmed as it stands
 					nB = bytesB = 0;
 					onA = true;
-					mp = A.first;
+					mp = firstA;
 					jm = offA = 0;
 					exit_cur = A.exit;
 				}
@@ -972,38 +1037,48 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 			OTZ_K1_MARK (4);
 			// ---- acceptance: lanes up to the first one whose path does not simply run on
 			const u64 termm = otz_ballot (OTZ_X_KIND (exit_cur) != OTZ_X_NORMAL);
-			const u32 F = termm ? otz_ctz64 (termm) : 63u; // last accepted lane
-			const bool acc = lane <= F;
+			u32 F = termm ? otz_ctz64 (termm) : 63u; // last accepted lane
+			bool acc = lane <= F;
 			// items: walk B's checkpoint rows, then (on walk A's path, with tokens left there) one
 			// item at the landing point and walk A's rows behind it
 			const u32 nB_items = (nB + OTZ_IX_G - 1u) / OTZ_IX_G;
-			const bool tailA = onA && jm < A.n;
+			const bool tailA = onA && jm < A.cnt;
 			const u32 rA0 = jm / OTZ_IX_G + 1u; // first row of walk A behind the landing point
 			const u32 nA_rows = tailA && nckA > rA0 ? nckA - rA0 : 0u;
-			const u32 cnt = acc ? nB_items + (tailA ? 1u + nA_rows : 0u) : 0u;
-			const u32 bytes = acc ? bytesB + (onA ? A.bytes - offA : 0u) : 0u;
-			const u32 bincl = otz_wave_scan_incl (bytes);
-			const u32 cincl = otz_wave_scan_incl (cnt);
-			const u32 produced = otz_readlane (bincl, 63u), n_new = otz_readlane (cincl, 63u);
-			const u32 fkind = OTZ_X_KIND (otz_readlane (exit_cur, F));
+			const u32 cnt_all = nB_items + (tailA ? 1u + nA_rows : 0u);
+			const u32 bytes_all = bytesB + (onA ? A.bytes - offA : 0u);
+			u32 cnt = acc ? cnt_all : 0u, bytes = acc ? bytes_all : 0u;
+			u32 bincl = otz_wave_scan_incl (bytes);
+			u32 cincl = otz_wave_scan_incl (cnt);
 			// the stream wants more than uncomp_size bytes (ref: pending copy/literal, Z_OK) --
 			// unless it breaks before that point
 			const u32 room = out_cap - opos;
 			const u64 overm = otz_ballot (acc && bincl > room);
 			if (overm != 0) {
 				// A lane's path crosses the end of the output.  The reference fills the buffer, keeps the
-				// rest of the token pending and returns Z_OK (:693-760, :805-830).  The round is indexed
-				// again, token by token, below (cold path: nothing of this round's state is needed there).
+				// rest of the token pending and returns Z_OK (:693-760, :805-830).  The lanes in front of
+				// that one are accepted as they are; its own segment is indexed again, token by token,
+				// below (cold path).
+				const u32 Fo = otz_ctz64 (overm);
 				serial_finish = true;
-				break;
+				acc = lane < Fo;
+				cnt = acc ? cnt_all : 0u;
+				bytes = acc ? bytes_all : 0u;
+				bincl = otz_wave_scan_incl (bytes);
+				cincl = otz_wave_scan_incl (cnt);
+				F = Fo; // (the lane the stream goes on in)
 			}
-			if (fkind == OTZ_X_INVALID || fkind == OTZ_X_TRUNC) {
-				status = OZG_ST_DATA; // ref: Z_DATA_ERROR from get_bit / no matching code
-				break;
-			}
-			if (fkind == OTZ_X_TRUNC_END) {
-				status = OZG_ST_BUF;
-				break;
+			const u32 produced = otz_readlane (bincl, 63u), n_new = otz_readlane (cincl, 63u);
+			const u32 fkind = OTZ_X_KIND (otz_readlane (exit_cur, F));
+			if (!serial_finish) {
+				if (fkind == OTZ_X_INVALID || fkind == OTZ_X_TRUNC) {
+					status = OZG_ST_DATA; // ref: Z_DATA_ERROR from get_bit / no matching code
+					break;
+				}
+				if (fkind == OTZ_X_TRUNC_END) {
+					status = OZG_ST_BUF;
+					break;
+				}
 			}
 			if (n_items + n_new + 1u > items_cap) {
 				status = OTZ_IX_OVERFLOW;
@@ -1015,17 +1090,26 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 				const u32 bit0 = (u32) ((u64) (8 * slot0) - block_bit); // block-relative bit position of this lane's slot bit 0
 				const u32 obase = opos - block_out + bincl - bytes;
 				otz_ix_item *dst = items + n_items + (cincl - cnt);
+				// (rows several at a time: the loads of a batch are in flight together -- one trip to memory per
+				// batch, not per row; every lane loads: a row it does not need is row 0, which exists)
 				if (otz_ballot (acc && nB_items != 0) != 0) {
-#pragma unroll 2
-					for (u32 r = 0; r < OTZ_K1_ROWS; r++) {
-						if (otz_ballot (acc && r < nB_items) == 0) {
+					for (u32 r0 = 0; r0 < rowsB_cap; r0 += 4u) {
+						if (otz_ballot (acc && r0 < nB_items) == 0) {
 							break; // (no lane has that many rows)
 						}
-						if (acc && r < nB_items) {
-							otz_ix_item it = rowsB[r * 64u + otz_opaque (lane)];
-							it.bit += bit0;
-							it.out += obase;
-							dst[r] = it;
+						otz_ix_item t[4];
+#pragma unroll
+						for (u32 k = 0; k < 4u; k++) {
+							t[k] = *otz_k1_row (rowsB, acc && r0 + k < nB_items ? r0 + k : 0u, 8u * otz_opaque (lane));
+						}
+#pragma unroll
+						for (u32 k = 0; k < 4u; k++) {
+							if (acc && r0 + k < nB_items) {
+								otz_ix_item it = t[k];
+								it.bit += bit0;
+								it.out += obase;
+								dst[r0 + k] = it;
+							}
 						}
 					}
 				}
@@ -1035,31 +1119,48 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 					it.out = obase + bytesB;
 					dst[nB_items] = it;
 				}
-#pragma unroll 4
-				for (u32 r = 1; r < OTZ_K1_ROWS; r++) {
-					if (otz_ballot (acc && tailA && r < nckA) == 0) {
+				for (u32 r0 = 1; r0 < rowsA_cap; r0 += 8u) {
+					if (otz_ballot (acc && tailA && r0 < nckA) == 0) {
 						break; // (walk A's paths are shorter than that)
 					}
-					if (acc && tailA && r >= rA0 && r < nckA) {
-						otz_ix_item it = rowsA[r * 64u + otz_opaque (lane)];
-						it.bit += bit0;
-						it.out += obase + bytesB - offA;
-						dst[nB_items + 1u + r - rA0] = it;
+					otz_ix_item t[8];
+#pragma unroll
+					for (u32 k = 0; k < 8u; k++) {
+						const u32 r = r0 + k;
+						t[k] = *otz_k1_row (rowsA, acc && tailA && r >= rA0 && r < nckA ? r : 0u, 8u * otz_opaque (lane));
+					}
+#pragma unroll
+					for (u32 k = 0; k < 8u; k++) {
+						const u32 r = r0 + k;
+						if (acc && tailA && r >= rA0 && r < nckA) {
+							otz_ix_item it = t[k];
+							it.bit += bit0;
+							it.out += obase + bytesB - offA;
+							dst[nB_items + 1u + r - rA0] = it;
+						}
 					}
 				}
 			}
 			OTZ_K1_MARK (5);
 			n_items += n_new;
 			opos += produced;
+			const u64 fslot_bit = (u64) (8 * ((int64_t)rb + (int64_t) (S / 8u) * (int64_t)F - (int64_t) (OTZ_K1_WARM / 8u)));
+			if (serial_finish) {
+				abs_bit = fslot_bit + otz_readlane (t, F); // lane F's true start
+				break;
+			}
 			// where the stream goes on (lane F's exit), and how the block ends
 			const u32 fexit = otz_readlane (exit_cur, F);
-			const u32 ftstart = otz_readlane (onA ? A.tstart : tstartB, F);
-			const u64 fslot_bit = (u64) (8 * ((int64_t)rb + (int64_t) (OTZ_K1_S / 8u) * (int64_t)F - (int64_t) (OTZ_K1_WARM / 8u)));
+			const u32 ftstart = otz_readlane (onA ? A.u : tstartB, F);
 			abs_bit = fslot_bit + OTZ_X_POS (fexit);
 			if (fkind == OTZ_X_EOB) {
 				block_done = true;
 				eob_abs = fslot_bit + ftstart;
 				end_bit = (u32) (eob_abs - block_bit);
+				// the next block's first span: what this block took, and a little more
+				const u64 took = abs_bit - block_bit;
+				span_cap = took + (took >> 4) + 2048u;
+				span_cap = span_cap < 64ull * OTZ_K1_SMIN ? 64ull * OTZ_K1_SMIN : span_cap;
 			} else {
 				end_bit = (u32) (abs_bit - block_bit);
 			}
@@ -1171,7 +1272,10 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 		for (u32 i = 0; i < 10; i++) {
 			prof[i] = pc[i];
 		}
-		prof[15] = otz_cycles () - pstart;
+		prof[10] = pstart; // (timeline diagnostics: start, end, place)
+		prof[11] = otz_cycles ();
+		prof[12] = otz_where ();
+		prof[15] = prof[11] - pstart;
 	}
 	return status == OTZ_IX_OVERFLOW;
 }

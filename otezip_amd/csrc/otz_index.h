@@ -5,7 +5,7 @@
 // decode of an entry is split (ref path: inflate(), src/lib/deflate-dec.inc.c:547-831):
 //
 //   otz_index_kernel (otz_huff_index.h): ONE WAVEFRONT per entry, no workgroup barriers,
-//     12 KB of LDS -> many entries per CU.  It finds the token chain -- where every token
+//     8 KB of LDS -> many entries per CU.  It finds the token chain -- where every token
 //     starts and how many output bytes precede it -- and writes that down as an INDEX:
 //     per DEFLATE block the code lengths and a flat list of items, one every <= OTZ_IX_G
 //     tokens: (bit position, output position).  It produces no output bytes.
@@ -66,14 +66,31 @@ struct otz_ix_item {
 
 #define OTZ_IX_ITEMS_OFF (32u + OTZ_IX_LENS)
 
-// what a region must hold besides the records: the speculative checkpoint rows of the index
-// kernel (two walks x OTZ_K1_ROWS rows x 64 lanes x 8 bytes), at the region's end
-#define OTZ_K1_ROWS 12u
-#define OTZ_K1_TEMP_BYTES (2u * OTZ_K1_ROWS * 64u * 8u)
+// Geometry of the index kernel's speculation (otz_huff_index.h): a span of the input is cut into 64
+// segments of S bits, one per lane, S a multiple of 32 between OTZ_K1_SMIN and OTZ_K1_SMAX.
+#define OTZ_K1_SMIN 256u
+#define OTZ_K1_SMAX 4096u
+OTZ_DEV u32 otz_k1_seg_bits(u64 span_bits) {
+	u64 s = (((span_bits + 63u) >> 6) + 31u) & ~(u64)31u;
+	return s < OTZ_K1_SMIN ? OTZ_K1_SMIN : s > OTZ_K1_SMAX ? OTZ_K1_SMAX : (u32)s;
+}
+// What a region must hold besides the records: the checkpoint rows of the index kernel's two walks
+// ([row][lane], 64 lanes x 8 bytes per row), at the region's end.  A lane notes a checkpoint every
+// OTZ_IX_G tokens: rows for one token per 4 bits of the longest segment the entry can have (a lane
+// that needs more closes its span early -- that costs time, never correctness); the re-walks of a
+// span's fixpoint rarely go beyond a few dozen tokens.
+#define OTZ_K1_ROWS_B 32u
+OTZ_DEV u32 otz_k1_rows_a(u32 comp_size) { return otz_k1_seg_bits ((u64)comp_size * 8u) / 32u + 2u; }
+OTZ_DEV u32 otz_k1_rows_b(u32 comp_size) {
+	const u32 a = otz_k1_rows_a (comp_size);
+	return a < OTZ_K1_ROWS_B ? a : OTZ_K1_ROWS_B;
+}
+OTZ_DEV u32 otz_k1_temp_bytes(u32 comp_size) { return (otz_k1_rows_a (comp_size) + otz_k1_rows_b (comp_size)) * 512u; }
+#define OTZ_K1_TEMP_MAX ((OTZ_K1_SMAX / 32u + 2u + OTZ_K1_ROWS_B) * 512u)
 
 // bytes of arena an entry asks for: records for one item per OTZ_IX_G output bytes in the
 // worst case (a stream of literals), one lane head per 64 bytes of input, block records, temp
 OTZ_DEV u64 otz_ix_region_bytes(u32 comp_size, u32 uncomp_size) {
-	u64 b = (u64)uncomp_size + (comp_size >> 1) + 4096u + OTZ_K1_TEMP_BYTES;
+	u64 b = (u64)uncomp_size + (comp_size >> 1) + 4096u + otz_k1_temp_bytes (comp_size);
 	return (b + 255u) & ~(u64)255u;
 }

@@ -121,7 +121,7 @@ otz_index_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, u32 first, u3
 }
 
 // the same with per-phase cycle counters (diagnostics: tools/prof_phases.py)
-extern "C" __global__ void __launch_bounds__ (64)
+extern "C" __global__ void __launch_bounds__ (64) __attribute__ ((amdgpu_waves_per_eu (OTZ_K1_WPE, 8)))
 otz_index_prof_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, u32 first, u32 n, u64 src_len, u64 dst_len, ozg_limits lim, u8 *arena, const otz_region *regions, otz_ix_head *heads,
 	u32 *ovf, u64 *prof) {
 	otz_index_body<true> (src, dst, entries, first, n, src_len, dst_len, lim, arena, regions, heads, ovf, prof);
@@ -533,6 +533,8 @@ constexpr int N_SLOTS = 8; // asynchronous staged batches in flight per device (
 std::mutex g_mu; // contexts, their buffers and slots
 u32 g_chunks = 1; // chunks of a large DEFLATE batch on two internal streams (OTEZIP_GPU_CHUNKS; 0 = cut at a whole number of index-kernel generations): neither measured faster than one launch pair (4.13 ms; 4 chunks 4.43, generation cut 4.14), kept for experiments
 ozg_limits g_limits = { 1000ull, 1024ull * 1024ull };
+bool g_dbg_index_only = false; // diagnostics (OTEZIP_DEBUG_INDEX_ONLY=1): a DEFLATE batch stops behind its index kernel -- for timing experimental
+                               // builds of that kernel whose index the apply kernel could not use; results are NOT produced
 u64 *g_prof = nullptr; // diagnostics: per-entry phase cycle counters (ozg_debug_set_profile_buffer)
 thread_local char g_err[256] = "";
 thread_local int g_cur = -1; // this thread's device (ozg_init / ozg_use_device)
@@ -709,8 +711,10 @@ int staging_reserve(staging &s, size_t src, size_t dst, size_t ent, size_t res) 
 // bounded by the buffer sizes (dst regions do not overlap).  Entries that find the arena
 // full are decoded by the self-contained kernel instead.
 int ws_reserve(workspace &ws, uint64_t src_len, uint64_t dst_len, uint32_t n) {
-	const size_t per_entry = 4096u + OTZ_K1_TEMP_BYTES + 256u;
-	size_t want = (size_t)dst_len + (size_t) (src_len >> 1) + (size_t)n * per_entry;
+	// (the checkpoint rows of an entry: 16 bytes per 64 bits of its payload and a fixed part, at most OTZ_K1_TEMP_MAX)
+	const size_t per_entry = 4096u + 256u + (OTZ_K1_ROWS_B + 3u) * 512u;
+	const size_t temp_max = (size_t)n * OTZ_K1_TEMP_MAX, temp_est = (size_t) (src_len << 1) + (size_t)n * 4096u;
+	size_t want = (size_t)dst_len + (size_t) (src_len >> 1) + (size_t)n * per_entry + (temp_est < temp_max ? temp_est : temp_max);
 	if (want > ((size_t)8 << 30)) {
 		want = (size_t)8 << 30; // beyond that, the overflow path takes what does not fit
 	}
@@ -820,6 +824,11 @@ int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, 
 			hipLaunchKernelGGL (g_prof ? otz_index_prof_kernel : otz_index_kernel, dim3 (n), dim3 (64), sizeof (otz_k1_lds), s, (const u8 *)d_src, (u8 *)d_dst, d_entries, 0u, n,
 				(u64)src_len, (u64)dst_len, g_limits, ws.arena, ws.regions, ws.heads, ws.ovf, g_prof);
 			OZG_HIP (hipGetLastError ());
+			if (g_dbg_index_only) {
+				OZG_HIP (hipEventRecord (ws.done, s));
+				ws.busy = true;
+				return OZG_OK;
+			}
 			hipLaunchKernelGGL (otz_apply_kernel, dim3 (n), dim3 (OTZ_NT), sizeof (otz_apply_lds), s, (const u8 *)d_src, (u8 *)d_dst,
 				d_entries, d_results, 0u, n, (u64)src_len, (u64)dst_len, g_limits, (const u8 *)ws.arena, ws.regions, ws.heads, g_prof, d_end_bits);
 			OZG_HIP (hipGetLastError ());
@@ -1083,6 +1092,9 @@ int ozg_init(int device) {
 		(void)hipOccupancyMaxActiveBlocksPerMultiprocessor (&per_cu, otz_zstd_kernel, 64, sizeof (otz_zs_lds));
 		g_dev[device].zs_grid = (u32) (cus > 0 ? cus : 256) * (u32) (per_cu > 0 ? per_cu : 12);
 		g_dev[device].ready = true;
+	}
+	if (const char *c = getenv ("OTEZIP_DEBUG_INDEX_ONLY")) {
+		g_dbg_index_only = atoi (c) != 0;
 	}
 	if (const char *c = getenv ("OTEZIP_GPU_CHUNKS")) {
 		const int v = atoi (c);
@@ -1427,12 +1439,49 @@ int ozg_encode_submit_packed(const void *h_src, uint64_t src_len, void *h_dst, u
 	return encode_submit (h_src, src_len, h_dst, dst_len, entries, h_results, n, job, true);
 }
 
+// Second step of a packed encode job, once job->mid has been reached: the packed payload's size is known now,
+// so its device-to-host copy can be issued (and job->done recorded behind it).  The job's device is current.
+static hipError_t job_second_step(ozg_job *job) {
+	uint64_t total = 0;
+	memcpy (&total, (const u8 *)job->h_ent + job->total_at, sizeof (total));
+	if (total > job->dst_len) {
+		total = job->dst_len; // (cannot happen: every payload fits its slot)
+	}
+	hipError_t e = hipSuccess;
+	if (total) {
+		e = hipMemcpyAsync (job->h_dst, job->st.d_pack, (size_t)total, hipMemcpyDeviceToHost, job->stream);
+	}
+	if (e == hipSuccess) {
+		e = hipEventRecord (job->done, job->stream);
+	}
+	if (e == hipSuccess) {
+		std::lock_guard<std::mutex> lk (g_mu);
+		job->two_step = false;
+	}
+	return e;
+}
+
 int ozg_job_done(ozg_job *job) {
 	if (!job || !job->busy) {
 		return 1;
 	}
 	if (job->two_step) {
-		return 0; // (its payload copy is only issued by ozg_job_wait)
+		// a packed encode job: its payload copy can only be issued once the sizes are back.  A poll that finds
+		// them back issues it; the job is done when that copy is.
+		if (hipEventQuery (job->mid) != hipSuccess) {
+			return 0;
+		}
+		const int keep = g_cur;
+		if (hipSetDevice (phys_of (job->dev)) != hipSuccess) {
+			return 0;
+		}
+		const hipError_t e = job_second_step (job);
+		if (keep >= 0 && keep != job->dev) {
+			(void)hipSetDevice (phys_of (keep));
+		}
+		if (e != hipSuccess) {
+			return 1; // (ozg_job_wait reports the error)
+		}
 	}
 	return hipEventQuery (job->done) == hipSuccess ? 1 : 0;
 }
@@ -1449,17 +1498,7 @@ int ozg_job_wait(ozg_job *job) {
 	if (job->two_step) {
 		e = hipEventSynchronize (job->mid);
 		if (e == hipSuccess) {
-			uint64_t total = 0;
-			memcpy (&total, (const u8 *)job->h_ent + job->total_at, sizeof (total));
-			if (total > job->dst_len) {
-				total = job->dst_len; // (cannot happen: every payload fits its slot)
-			}
-			if (total) {
-				e = hipMemcpyAsync (job->h_dst, job->st.d_pack, (size_t)total, hipMemcpyDeviceToHost, job->stream);
-			}
-			if (e == hipSuccess) {
-				e = hipEventRecord (job->done, job->stream);
-			}
+			e = job_second_step (job);
 		}
 	}
 	if (e == hipSuccess) {

@@ -27,6 +27,9 @@
 #ifndef OTZ_A_WIN
 #define OTZ_A_WIN 4096u   // bytes before the round kept in LDS (a multiple of 16)
 #endif
+#ifndef OTZ_A_RES_LANES
+#define OTZ_A_RES_LANES OTZ_NT // work-items that resolve the round's matches (whole wavefronts; the others wait at the barrier)
+#endif
 #define OTZ_A_RBUF (OTZ_A_WIN + 16u + OTZ_A_RMAX) // + the last, partial 16-byte chunk before the window
 #define OTZ_A_FIN_WORDS (OTZ_A_RBUF / 32u + 2u)
 
@@ -77,10 +80,12 @@ struct otz_a_pos {
 // `list` (buffer positions, u16): a prefix sum over the lanes' match counts gives every lane
 // its slice.  Returns the number of matches of the round.  All OTZ_NT work-items.
 static_assert (OTZ_IX_G == 8u, "eight 16-bit destinations are packed into four 32-bit registers");
-static_assert (OTZ_NT * OTZ_IX_G * 2u <= OTZ_STAGE_BYTES, "the match list of a round fits the stage buffer");
-OTZ_DEV u32 otz_place_items(otz_apply_lds &L, bool active, u32 s_bit, u32 e_bit, u32 ri, u32 p0, u16 *list) {
+#define OTZ_A_LIST_CAP (OTZ_NT * OTZ_IX_G) // matches of a round, at most
+static_assert (OTZ_A_LIST_CAP * 2u <= OTZ_STAGE_BYTES, "the match lists of a round fit the stage buffer");
+OTZ_DEV u32 otz_place_items(otz_apply_lds &L, bool active, u32 s_bit, u32 e_bit, u32 ri, u32 p0, u16 *list, u32 *n_far) {
 	u32 nm = 0;
 	u32 k0 = 0, k1 = 0, k2 = 0, k3 = 0; // the matches' destinations, newest in the low half of k0
+	u32 farm = 0;                       // bit k: the k-th newest match has its whole source before rbuf[0]
 	u32 err = 0;                        // 1: the index and the stream disagree, 2: distance beyond the output start
 	u32 pos = s_bit;
 	if (active) {
@@ -122,6 +127,7 @@ OTZ_DEV u32 otz_place_items(otz_apply_lds &L, bool active, u32 s_bit, u32 e_bit,
 				k2 = otz_alignbit (k2, k1, 16);
 				k1 = otz_alignbit (k1, k0, 16);
 				k0 = (k0 << 16) | ri;
+				farm = (farm << 1) | (dist >= ri + val ? 1u : 0u);
 				nm += 1u;
 				ri += val;
 				pos += used + dl + dxb;
@@ -143,18 +149,86 @@ OTZ_DEV u32 otz_place_items(otz_apply_lds &L, bool active, u32 s_bit, u32 e_bit,
 		L.dbg[3] = e_bit;
 		otz_set_status (L, OZG_ST_INTERNAL);
 	}
+	// two lists: the matches that (also) read the buffer in stream order from list[0] on, the ones that read only
+	// the entry's output in global memory from the end of the list's room downwards (in any order)
+	const u32 nf = otz_popc (farm), nn = nm - nf;
 	u32 total;
-	const u32 incl = otz_block_scan_incl (nm, L.scan, &total); // (two barriers: every stage read is done)
-	const u32 at = incl - nm;
+	const u32 incl = otz_block_scan_incl (nn | (nf << 16), L.scan, &total); // (two barriers: every stage read is done)
+	const u32 at_n = (incl & 0xFFFFu) - nn, at_f = (incl >> 16) - nf;
 	// match number q (in stream order) is the (nm - 1 - q)-th newest
 #pragma unroll
 	for (u32 k = 0; k < OTZ_IX_G; k++) {
 		if (k < nm) {
 			const u32 w = k < 2u ? k0 : k < 4u ? k1 : k < 6u ? k2 : k3;
-			list[at + nm - 1u - k] = (u16) (w >> (16u * (k & 1u)));
+			const u32 older_far = otz_popc (farm >> (k + 1u));
+			const bool isfar = ((farm >> k) & 1u) != 0;
+			const u32 idx = isfar ? OTZ_A_LIST_CAP - 1u - (at_f + otz_popc (farm & ((1u << k) - 1u))) : at_n + (nm - 1u - k) - older_far;
+			list[idx] = (u16) (w >> (16u * (k & 1u)));
 		}
 	}
-	return total;
+	*n_far = total >> 16;
+	return total & 0xFFFFu;
+}
+
+// The matches whose source lies wholly before rbuf[0]: those bytes were final, and in global memory, before the
+// round began, so these copies depend on nothing and are made first, all of a lane's loads in flight together --
+// one trip to the L2 per round instead of one inside every iteration of the resolution loop below.
+OTZ_DEV void otz_far_copies(otz_apply_lds &L, const otz_job &J, u32 p0, const u16 *list, u32 n_far) {
+	for (u32 m = otz_tid (); m < n_far; m += OTZ_NT) {
+		u32 o = list[OTZ_A_LIST_CAP - 1u - m];
+		const u64 dw = otz_ld64u (&L.rbuf[o & ~3u]);
+		const u32 cd = otz_alignbyte ((u32) (dw >> 32), (u32)dw, o) & 0xFFFFFFu;
+		u32 pend = (cd >> 15) + 3u;
+		const u8 *g = J.out + (p0 + o - ((cd & 0x7FFFu) + 1u)); // (>= J.out: the distance was checked against the position)
+		while (pend != 0) {
+			const u32 n = pend < 16u ? pend : 16u;
+			const u32 *gp = reinterpret_cast<const u32 *> ((uintptr_t)g & ~(uintptr_t)3);
+			const u32 q = (u32) (uintptr_t)g & 3u;
+			const u32 span = q + n; // 1..19: only the words that hold bytes of the source (they lie inside the entry's output)
+			const u32 s0 = gp[0];
+			const u32 s1 = span > 4u ? gp[1] : 0u;
+			const u32 s2 = span > 8u ? gp[2] : 0u;
+			const u32 s3 = span > 12u ? gp[3] : 0u;
+			const u32 s4 = span > 16u ? gp[4] : 0u;
+			const u64 lo = otz_alignbyte (s1, s0, q) | ((u64)otz_alignbyte (s2, s1, q) << 32);
+			const u64 hi = otz_alignbyte (s3, s2, q) | ((u64)otz_alignbyte (s4, s3, q) << 32);
+			u8 *dst = &L.rbuf[o];
+			u64 v = lo;
+			if (n & 16u) {
+				otz_st64u (dst, lo);
+				otz_st64u (dst + 8, hi);
+			} else {
+				if (n & 8u) {
+					otz_st64u (dst, lo);
+					v = hi;
+					dst += 8;
+				}
+				if (n & 4u) {
+					otz_st16u (dst, (u16)v);
+					otz_st16u (dst + 2, (u16) (v >> 16));
+					v >>= 32;
+					dst += 4;
+				}
+				if (n & 2u) {
+					otz_st16u (dst, (u16)v);
+					v >>= 16;
+					dst += 2;
+				}
+				if (n & 1u) {
+					*dst = (u8)v;
+				}
+			}
+			otz_order_stores ();
+			const u64 mask = (((u64)1 << n) - 1u) << (o & 31u);
+			otz_lds_or (&L.fin[o >> 5], (u32)mask);
+			if ((u32) (mask >> 32)) {
+				otz_lds_or (&L.fin[(o >> 5) + 1u], (u32) (mask >> 32));
+			}
+			o += n;
+			g += n;
+			pend -= n;
+		}
+	}
 }
 
 // ---------------------------------------------------------------- LZ77 resolution
@@ -176,6 +250,12 @@ OTZ_DEV void otz_resolve_list(otz_apply_lds &L, const otz_job &J, u32 p0, const 
 	u32 pend = 0, pdist = 1, o = 0;
 	int si = 0; // buffer position of the source; negative: before the buffer
 	u32 spins = 0;
+#ifdef OTZ_RES_PROF // diagnostics: where an iteration's time goes (every wait drained at the marks: slots 1, 5, 6, 9)
+	u64 rp0 = 0, rp1 = 0, rp2 = 0, rp3 = 0, rpt = otz_cycles ();
+#define OTZ_RP(acc) do { asm volatile ("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const u64 _t = otz_cycles (); acc += _t - rpt; rpt = _t; } while (0)
+#else
+#define OTZ_RP(acc) do { } while (0)
+#endif
 	for (;;) {
 		OTZ_COUNT (L, J, OTZ_P_B_ITERS, 1);
 		if (pend == 0 && m < n_matches) {
@@ -186,8 +266,9 @@ OTZ_DEV void otz_resolve_list(otz_apply_lds &L, const otz_job &J, u32 p0, const 
 			pdist = (cd & 0x7FFFu) + 1u;
 			pend = (cd >> 15) + 3u;
 			si = (int)o - (int)pdist;
-			m += OTZ_NT;
+			m += OTZ_A_RES_LANES;
 		}
+		OTZ_RP (rp0);
 		// ---- one step: up to 16 bytes that neither overlap their own source nor straddle rbuf[0]
 		u32 n = pend < 16u ? pend : 16u;
 		n = n < pdist ? n : pdist;
@@ -201,6 +282,7 @@ OTZ_DEV void otz_resolve_list(otz_apply_lds &L, const otz_job &J, u32 p0, const 
 		otz_order_loads (); // "flag, then data": the source bytes are read after the bits that declare them final
 		const u64 need = b > a ? (((u64)1 << (b - a)) - 1u) << (a & 31u) : 0u;
 		const bool go = pend != 0 && (have & need) == need;
+		OTZ_RP (rp1);
 		if (go) {
 			// the source bytes: dword-aligned reads, then a byte funnel shift (LDS reads past the bytes
 			// used land in the buffer's slack and are ignored)
@@ -270,6 +352,7 @@ OTZ_DEV void otz_resolve_list(otz_apply_lds &L, const otz_job &J, u32 p0, const 
 			si += dbl ? 0 : (int)n;
 			pdist += dbl ? n : 0u;
 		}
+		OTZ_RP (rp2);
 		if (J.prof) { // diagnostics: lanes that copied / lanes that had a match in hand, this iteration (wavefront 0)
 			const u32 ng = otz_popc64 (otz_ballot (go)), np = otz_popc64 (otz_ballot (go || pend != 0));
 			OTZ_COUNT (L, J, 11, ng);
@@ -297,7 +380,14 @@ OTZ_DEV void otz_resolve_list(otz_apply_lds &L, const otz_job &J, u32 p0, const 
 				}
 			}
 		}
+		OTZ_RP (rp3);
 	}
+#ifdef OTZ_RES_PROF
+	OTZ_COUNT (L, J, 1, rp0);
+	OTZ_COUNT (L, J, 5, rp1);
+	OTZ_COUNT (L, J, 6, rp2);
+	OTZ_COUNT (L, J, 9, rp3);
+#endif
 }
 
 // ---------------------------------------------------------------- rounds
@@ -524,13 +614,17 @@ OTZ_DEV void otz_apply_entry(otz_apply_lds &L, const otz_job &J, const otz_ix_he
 			const u32 s_bit = p0 + (a.bit - first.bit), e_bit = p0 + (z.bit - first.bit);
 			// the match list takes over the stage buffer once every lane has read its tokens
 			u16 *const list = reinterpret_cast<u16 *> (L.stage);
-			const u32 n_matches = otz_place_items (L, tid < n, s_bit, e_bit, P.opos - P.p0 + (a.out - first.out), P.p0, list);
+			u32 n_far = 0;
+			const u32 n_matches = otz_place_items (L, tid < n, s_bit, e_bit, P.opos - P.p0 + (a.out - first.out), P.p0, list, &n_far);
 			otz_sync ();
 			OTZ_MARK (L, J, OTZ_P_EMIT);
 			if (otz_get_status (L) != 0) {
 				break;
 			}
-			otz_resolve_list (L, J, P.p0, list, n_matches);
+			otz_far_copies (L, J, P.p0, list, n_far);
+			if (OTZ_A_RES_LANES == OTZ_NT || tid < OTZ_A_RES_LANES) {
+				otz_resolve_list (L, J, P.p0, list, n_matches);
+			}
 			otz_sync ();
 			OTZ_MARK (L, J, OTZ_P_RESOLVE);
 			if (otz_get_status (L) != 0) {

@@ -289,6 +289,12 @@ OTZ_DEV void otz_lzma_run(const u8 *in, u32 n_in, u8 *out, u32 cap, u32 eflags, 
 		res->crc32 = 0;
 		res->flags = 0;
 		*route = 2u; // OTZ_ZS_ROUTE_DONE: the CRC pass follows
+	} else if (st == OZG_ST_SIZE && (eflags & OZG_EF_SIZE_IS_CAP)) {
+		res->status = OZG_ST_SIZE; // the codec seam: valid so far, out of room (see otz_brotli_run)
+		res->total_out = 0;
+		res->crc32 = 0;
+		res->flags = 0;
+		*route = 2u;
 	} else {
 		*route = 1u; // OTZ_ZS_ROUTE_PRIVATE: the reference's token decoder has the last word
 	}

@@ -111,6 +111,10 @@ OTZ_DEV void otz_set_priority_normal() { __builtin_amdgcn_s_setprio (0); }
 
 // shader clock, for the diagnostic phase counters only
 OTZ_DEV u64 otz_cycles() { return __builtin_readcyclecounter (); }
+// where this wavefront runs (diagnostics): HW_REG_HW_ID in the low word (wave, SIMD, CU, SH, SE), HW_REG_XCC_ID in the high one
+OTZ_DEV u64 otz_where() {
+	return (u64)__builtin_amdgcn_s_getreg ((31 << 11) | 4) | ((u64)__builtin_amdgcn_s_getreg ((31 << 11) | 20) << 32);
+}
 
 OTZ_DEV u32 otz_popc(u32 v) { return (u32)__popc (v); }
 OTZ_DEV u32 otz_popc64(u64 v) { return (u32)__popcll (v); }
@@ -155,6 +159,7 @@ OTZ_DEV void otz_order_stores() { asm volatile ("" ::: "memory"); }
 // Forces a loaded value to be materialised HERE: keeps the compiler from sinking an LDS load
 // below a branch, where it would start a second dependent round trip.
 OTZ_DEV void otz_touch64(u64 &v) { asm volatile ("" : "+v"(v)); }
+OTZ_DEV void otz_touch32(u32 &v) { asm volatile ("" : "+v"(v)); }
 // Hides a value's origin from the optimiser: stops it from computing per-lane constants
 // once in the kernel prologue and keeping them alive (spilled) across everything else.
 // "Uses" a value without doing anything: the load that produced it has to have returned by here.

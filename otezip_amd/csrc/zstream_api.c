@@ -358,6 +358,13 @@ static int ozs_decode(z_stream *strm) {
 			return Z_STREAM_END;
 		}
 		free (out);
+		if (rc == OZG_OK && r.status == OZG_ST_SIZE) {
+			/* a stream of the real format, valid as far as the room went: the caller's buffer is too small.
+			 * Nothing is consumed or written; a caller that grows its buffer and calls again (the reference's
+			 * CLI does: ref src/main.c:612-650) gets the stream then.  (Falling through to the reference's
+			 * container decoder would answer Z_DATA_ERROR for a valid stream.) */
+			return Z_BUF_ERROR;
+		}
 	}
 	if (st->method != OZG_METHOD_DEFLATE && st->method != OZG_METHOD_LZMA) {
 		long long plen = st->method == OZG_METHOD_ZSTD ? ozs_zstd_content_size (in, (uInt)in_len) : -1;

@@ -362,6 +362,9 @@ extern "C" int emu_decode_batch_mode(const void *src, uint64_t src_len, void *ds
 		a.region_bytes = (u32)want;
 		a.phase = 1;
 		run_block (64, a, sizeof (otz_k1_lds));
+		if (getenv ("OTZ_EMU_TRACE")) {
+			fprintf (stderr, "[emu] entry %u: index status %d, %u blocks, %u bytes\n", i, head.status, head.n_blocks, head.total_out);
+		}
 		a.phase = 2;
 		run_block (OTZ_NT, a, sizeof (otz_apply_lds));
 		if (results[i].status == OZG_ST_OK) {

@@ -190,6 +190,7 @@ OTZ_DEV void otz_set_priority_high() {}
 OTZ_DEV void otz_set_priority_normal() {}
 
 OTZ_DEV u64 otz_cycles() { return 0; }
+OTZ_DEV u64 otz_where() { return 0; }
 OTZ_DEV u32 otz_popc(u32 v) { return (u32)__builtin_popcount (v); }
 OTZ_DEV u32 otz_popc64(u64 v) { return (u32)__builtin_popcountll (v); }
 OTZ_DEV u32 otz_brev(u32 v) {
@@ -222,6 +223,7 @@ OTZ_DEV void otz_st16u(void *p, u16 v) { memcpy (p, &v, 2); }
 OTZ_DEV void otz_order_loads() { __atomic_thread_fence (__ATOMIC_ACQUIRE); }
 OTZ_DEV void otz_order_stores() { __atomic_thread_fence (__ATOMIC_RELEASE); }
 OTZ_DEV void otz_touch64(u64 &v) { (void)v; }
+OTZ_DEV void otz_touch32(u32 &v) { (void)v; }
 OTZ_DEV void otz_consume(u32 v) { (void)v; }
 OTZ_DEV u32 otz_opaque(u32 v) { return v; }
 

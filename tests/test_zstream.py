@@ -332,8 +332,18 @@ def test_real_brotli_lzma1_and_lzfse_streams_through_the_seam(gpu_lib):
         for kind in ("lzvn", "lzfse", "mixed"):   # (LZFSE: checked against the model of the format, parity unpinned)
             ret, tin, tout, out = gpu_codec(L, "lzfse", True, M.encode(d, kind), len(d) + 777)
             assert ret == 1 and tout == len(d) and out[:tout] == d, ("lzfse", kind, len(d), ret, tout)
-    # a stream that needs more room than there is does not come out as a success
+    # a valid stream that needs more room than there is: Z_BUF_ERROR, nothing consumed or written, so that a caller
+    # that grows its buffer and calls again (the reference's CLI: ref src/main.c:612-650) gets it then -- not the
+    # Z_DATA_ERROR of the reference's container reader, which these bytes would get if they were handed on to it
+    d = datas[3]
+    big = []
     if B.available():
-        comp = B.compress(datas[3], quality=5)
-        ret, _, _, _ = gpu_codec(L, "brotli", True, comp, 1000)
-        assert ret != 1
+        big.append(("brotli", B.compress(d, quality=5)))
+    raw = lzma.compress(d, format=lzma.FORMAT_RAW, filters=f)
+    big.append(("lzma", b"\x09\x14\x05\x00" + bytes([(2 * 5 + 0) * 9 + 3]) + struct.pack("<I", 1 << 20) + raw))
+    big.append(("lzfse", M.encode(d, "mixed")))
+    for name, comp in big:
+        ret, tin, tout, _ = gpu_codec(L, name, True, comp, 1000)
+        assert ret == -5 and tin == 0 and tout == 0, (name, ret, tin, tout)
+        ret, tin, tout, out = gpu_codec(L, name, True, comp, len(d))
+        assert ret == 1 and out[:tout] == d, (name, ret, tout)
