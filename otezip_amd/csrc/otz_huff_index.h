@@ -666,11 +666,24 @@ OTZ_DEV void otz_k1_walk_loop(const otz_k1_lds &L, u32 lb, otz_k1_ws &W, u32 pen
 	}
 }
 
+// Entry byte of byte 0 of this lane's slot: the span starts in byte rb, a segment is sb bytes, the slot starts
+// OTZ_K1_WARM bits ahead of the segment.  (Computed where it is needed, from an opaque lane number: a per-lane
+// 64-bit value kept across the walks is two registers the kernel does not have.)
+OTZ_DEV int64_t otz_k1_slot0(u32 rb, u32 sb) {
+	return (int64_t)rb + (int64_t)sb * (int64_t)otz_opaque (otz_lane ()) - (int64_t) (OTZ_K1_WARM / 8u);
+}
+
+// The input ends at this slot-relative bit of the lane's slot (0: the slot lies behind the input).
+OTZ_DEV u32 otz_k1_limit(u32 n_in, u32 rb, u32 sb) {
+	const int64_t lb = 8 * ((int64_t)n_in - otz_k1_slot0 (rb, sb));
+	return lb <= 0 ? 0u : lb > 0xFFFFFF ? 0xFFFFFFu : (u32)lb;
+}
+
 // Stage piece k of every lane's slot: OTZ_K1_WROWS words from entry byte slot0 + k * P / 8 (zeros outside the
 // entry), each lane its own column of the window.
-OTZ_DEV void otz_k1_stage_piece(otz_k1_lds &L, const u8 *in, u32 n_in, int64_t slot0, u32 k) {
+OTZ_DEV void otz_k1_stage_piece(otz_k1_lds &L, const u8 *in, u32 n_in, u32 rb, u32 sb, u32 k) {
 	const u32 lane = otz_lane ();
-	const int64_t b = slot0 + (int64_t) (k * (OTZ_K1_P / 8u));
+	const int64_t b = otz_k1_slot0 (rb, sb) + (int64_t) (k * (OTZ_K1_P / 8u));
 	static_assert (OTZ_K1_WROWS % 4u == 2u, "whole 16-byte loads and half of one");
 #pragma unroll
 	for (u32 q = 0; q < (OTZ_K1_WROWS + 3u) / 4u; q++) {
@@ -694,9 +707,10 @@ OTZ_DEV void otz_k1_stage_piece(otz_k1_lds &L, const u8 *in, u32 n_in, int64_t s
 //     *offA bytes; firstA: walk A's first token) while that piece is still staged.
 // Ends with every lane's W.exit set.
 template <bool SPEC>
-OTZ_DEV void otz_k1_walk(otz_k1_lds &L, const u8 *in, u32 n_in, int64_t slot0, otz_k1_ws &W, bool run, u32 start, u32 s, u32 e, u32 limit,
+OTZ_DEV void otz_k1_walk(otz_k1_lds &L, const u8 *in, u32 n_in, u32 rb, u32 sb, otz_k1_ws &W, bool run, u32 start, u32 s, u32 e,
 	u32 ncap, otz_ix_item *rows, const otz_ix_item *rowsA, u64 bmA, u32 nckA, u32 firstA, u32 *first, u32 *jm, u32 *offA) {
 	const u32 lane = otz_lane ();
+	const u32 limit = otz_k1_limit (n_in, rb, sb);
 	// a token that starts in front of e ends in front of e + 48: the clamp changes nothing for
 	// tokens that exist and puts a reserved distance code (OTZ_K1_DBAD bits) beyond the limit
 	const u32 lim2 = limit < e + 48u ? limit : e + 48u;
@@ -727,7 +741,7 @@ OTZ_DEV void otz_k1_walk(otz_k1_lds &L, const u8 *in, u32 n_in, int64_t slot0, o
 		// (LDS only, and the LDS executes a wavefront's instructions in order: nothing has to drain -- in particular
 		// not the checkpoint stores, which stay in flight across pieces)
 		otz_wave_sync_lds (); // the previous piece (or the block prologue's scratch) is dead
-		otz_k1_stage_piece (L, in, n_in, slot0, k);
+		otz_k1_stage_piece (L, in, n_in, rb, sb, k);
 		otz_wave_sync_lds ();
 		if (SPEC && k == 0) {
 			// the warm-up: nothing is counted or noted, and a guess that runs into a code it cannot take moves on a bit
@@ -976,16 +990,13 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 			const u32 rb = (u32) (abs_bit >> 3), phi = (u32) (abs_bit & 7u);
 			const u64 left = total_bits - 8ull * rb;
 			const u32 S = otz_k1_seg_bits (left < span_cap ? left : span_cap);
-			const int64_t slot0 = (int64_t)rb + (int64_t) (S / 8u) * (int64_t)lane - (int64_t) (OTZ_K1_WARM / 8u); // entry byte of the slot's byte 0
-			// slot-relative bit coordinates: the lane's segment is [s, e)
+			// slot-relative bit coordinates: the lane's slot starts OTZ_K1_WARM bits ahead of its segment [s, e)
 			const u32 s = OTZ_K1_WARM + phi, e = s + S;
-			const int64_t lb = (int64_t)total_bits - 8 * slot0; // the input ends at this slot-relative bit
-			const u32 limit = lb <= 0 ? 0u : lb > 0xFFFFFF ? 0xFFFFFFu : (u32)lb;
 			OTZ_K1_COUNT (6);
 			// ---- walk A
 			otz_k1_ws A;
 			u32 firstA = OTZ_K1_NONE, dummy0 = 0, dummy1 = 0;
-			otz_k1_walk<true> (L, in, n_in, slot0, A, true, lane ? s - OTZ_K1_WARM : s, s, e, limit, rowsA_cap * OTZ_IX_G, rowsA, rowsA, 0, 0, 0, &firstA, &dummy0, &dummy1);
+			otz_k1_walk<true> (L, in, n_in, rb, S / 8u, A, true, lane ? s - OTZ_K1_WARM : s, s, e, rowsA_cap * OTZ_IX_G, rowsA, rowsA, 0, 0, 0, &firstA, &dummy0, &dummy1);
 			const u32 nckA = (A.cnt + OTZ_IX_G - 1u) / OTZ_IX_G; // checkpoint rows in front of tokens walk A took
 			OTZ_K1_MARK (3);
 			// ---- fixpoint over the true starts.  A lane's true path: nB tokens of its own walk B
@@ -1010,7 +1021,7 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 					OTZ_K1_COUNT (8);
 					otz_k1_ws W;
 					u32 unused = 0, j = 0, ob = 0;
-					otz_k1_walk<false> (L, in, n_in, slot0, W, rewalk, nt, s, e, limit, rowsB_cap * OTZ_IX_G, rowsB, rowsA, A.bm, nckA, firstA, &unused, &j, &ob);
+					otz_k1_walk<false> (L, in, n_in, rb, S / 8u, W, rewalk, nt, s, e, rowsB_cap * OTZ_IX_G, rowsB, rowsA, A.bm, nckA, firstA, &unused, &j, &ob);
 					if (rewalk) {
 						const bool early = W.merged && W.cpos != W.u;
 						nB = W.cnt;
@@ -1087,7 +1098,8 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 			// ---- the accepted lanes' items, in stream order.  Row by row: every load is
 			// independent of the others (and a row is one coalesced access).
 			{
-				const u32 bit0 = (u32) ((u64) (8 * slot0) - block_bit); // block-relative bit position of this lane's slot bit 0
+				// block-relative bit position of this lane's slot bit 0 (modulo 2^32: lane 0's may lie in front of the block)
+				const u32 bit0 = 8u * rb - OTZ_K1_WARM - (u32)block_bit + S * otz_opaque (lane);
 				const u32 obase = opos - block_out + bincl - bytes;
 				otz_ix_item *dst = items + n_items + (cincl - cnt);
 				// (rows several at a time: the loads of a batch are in flight together -- one trip to memory per
