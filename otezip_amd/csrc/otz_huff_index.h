@@ -589,8 +589,8 @@ struct otz_k1_ws {
 // computed and then not added.
 #define OTZ_K1_HALT 0x80000000u
 #define OTZ_K1_MERGE 0x40000000u
-#define OTZ_K1_RESTART 64u // tokens: a guessed chain that stops before it has come this far starts over
-template <bool SPEC, bool EARLY>
+#define OTZ_K1_YOUNG 768u // bits: a guessed chain that stops in the first so many bits of its segment starts over
+template <bool SPEC, bool EARLY, bool YOUNG>
 OTZ_DEV void otz_k1_walk_loop(const otz_k1_lds &L, u32 lb, otz_k1_ws &W, u32 pend, u32 s, u32 lim2, u32 ncap, otz_ix_item *rows,
 	const otz_ix_item *rowsA, u64 bmA, u32 nckA) {
 	const u32 lane8 = 8u * otz_opaque (otz_lane ());
@@ -600,10 +600,11 @@ OTZ_DEV void otz_k1_walk_loop(const otz_k1_lds &L, u32 lb, otz_k1_ws &W, u32 pen
 	// Walk A is a guess until it has met the real chain, and a guessed chain runs into an end-of-block code (or
 	// a reserved one) once in a few thousand tokens -- in one span out of four some lane does.  With segments
 	// this long that lane must not give up (its whole segment would be walked again, alone): it starts over
-	// one bit further on, as a new chain -- first token, counts, checkpoints and all.  Only early on: a chain
-	// that has come OTZ_K1_RESTART tokens far has met the real one, and what stops it then stops the block.
+	// one bit further on, as a new chain -- first token, counts, checkpoints and all.  Only early on (YOUNG: the
+	// first OTZ_K1_YOUNG bits of the segment, a loop of their own so that the rest of the walk does not carry the
+	// bookkeeping): a chain that has come that far has met the real one, and what stops it then stops the block.
 	// (Whatever walk A does is a hint: the true path is walk B's, up to where it lands on walk A's chain.)
-	const bool may_restart = SPEC && otz_lane () != 0;
+	const bool may_restart = SPEC && YOUNG && otz_lane () != 0;
 	while (u < pend && cnt < ncap) {
 		bool hit = false;
 		if (!SPEC) {
@@ -632,8 +633,8 @@ OTZ_DEV void otz_k1_walk_loop(const otz_k1_lds &L, u32 lb, otz_k1_ws &W, u32 pen
 		const u32 tend = u + h.nb;
 		const bool bad = h.stop || tend > lim2;
 		const bool adv = !bad && !hit;
-		if (SPEC) {
-			const bool again = may_restart && h.stop && tend <= lim2 && cnt < OTZ_K1_RESTART;
+		if (SPEC && YOUNG) {
+			const bool again = may_restart && h.stop && tend <= lim2;
 			bytes = again ? 0u : bytes + (adv ? h.ob : 0u);
 			cnt = again ? 0u : cnt + (adv ? 1u : 0u);
 			first = again ? u + 1u : first;
@@ -758,9 +759,13 @@ OTZ_DEV void otz_k1_walk(otz_k1_lds &L, const u8 *in, u32 n_in, u32 rb, u32 sb, 
 		}
 		if (k == 0) {
 			const u32 pe = s + 64u < pend ? s + 64u : pend;
-			otz_k1_walk_loop<SPEC, true> (L, lb, W, pe, s, lim2, ncap, rows, rowsA, bmA, nckA);
+			otz_k1_walk_loop<SPEC, true, SPEC> (L, lb, W, pe, s, lim2, ncap, rows, rowsA, bmA, nckA);
 		}
-		otz_k1_walk_loop<SPEC, false> (L, lb, W, pend, s, lim2, ncap, rows, rowsA, bmA, nckA);
+		if (SPEC && k * OTZ_K1_P < s + OTZ_K1_YOUNG) {
+			const u32 py = s + OTZ_K1_YOUNG < pend ? s + OTZ_K1_YOUNG : pend;
+			otz_k1_walk_loop<SPEC, false, true> (L, lb, W, py, s, lim2, ncap, rows, rowsA, bmA, nckA);
+		}
+		otz_k1_walk_loop<SPEC, false, false> (L, lb, W, pend, s, lim2, ncap, rows, rowsA, bmA, nckA);
 		// the lanes that stopped in this piece: how their walk ends
 		if (otz_ballot (W.halted) != 0) {
 			if (W.halted) {
