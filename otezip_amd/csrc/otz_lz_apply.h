@@ -27,8 +27,16 @@
 #ifndef OTZ_A_WIN
 #define OTZ_A_WIN 4096u   // bytes before the round kept in LDS (a multiple of 16)
 #endif
+// The resolution loop is a chain of dependent iterations (as many as the round's longest chain of matches copying
+// from matches: 5-25), so what counts is how long ONE iteration takes, and that is set by how many wavefronts of
+// the CU are in it: half of the workgroup's wavefronts resolve, at raised priority, the others wait at the barrier
+// and leave their issue slots to the bulk phases of the other workgroups.  Measured (ms per step of the
+// benchmark): 512 work-items 2.68, with priority 2.68; 256 with priority 2.57; 128 2.61; 192 / 320 2.59.
 #ifndef OTZ_A_RES_LANES
-#define OTZ_A_RES_LANES OTZ_NT // work-items that resolve the round's matches (whole wavefronts; the others wait at the barrier)
+#define OTZ_A_RES_LANES 256u // work-items that resolve the round's matches (whole wavefronts; the others wait at the barrier)
+#endif
+#ifndef OTZ_A_RES_PRIO
+#define OTZ_A_RES_PRIO 1
 #endif
 #define OTZ_A_RBUF (OTZ_A_WIN + 16u + OTZ_A_RMAX) // + the last, partial 16-byte chunk before the window
 #define OTZ_A_FIN_WORDS (OTZ_A_RBUF / 32u + 2u)
@@ -622,9 +630,15 @@ OTZ_DEV void otz_apply_entry(otz_apply_lds &L, const otz_job &J, const otz_ix_he
 				break;
 			}
 			otz_far_copies (L, J, P.p0, list, n_far);
+#if OTZ_A_RES_PRIO
+			otz_set_priority_high (); // (the resolution loop goes first, the bulk phases of the other workgroups fill the gaps)
+#endif
 			if (OTZ_A_RES_LANES == OTZ_NT || tid < OTZ_A_RES_LANES) {
 				otz_resolve_list (L, J, P.p0, list, n_matches);
 			}
+#if OTZ_A_RES_PRIO
+			otz_set_priority_normal ();
+#endif
 			otz_sync ();
 			OTZ_MARK (L, J, OTZ_P_RESOLVE);
 			if (otz_get_status (L) != 0) {
