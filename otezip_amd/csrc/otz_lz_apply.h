@@ -93,7 +93,7 @@ static_assert (OTZ_A_LIST_CAP * 2u <= OTZ_STAGE_BYTES, "the match lists of a rou
 OTZ_DEV u32 otz_place_items(otz_apply_lds &L, bool active, u32 s_bit, u32 e_bit, u32 ri, u32 p0, u16 *list, u32 *n_far) {
 	u32 nm = 0;
 	u32 k0 = 0, k1 = 0, k2 = 0, k3 = 0; // the matches' destinations, newest in the low half of k0
-	u32 farm = 0;                       // bit k: the k-th newest match has its whole source before rbuf[0]
+	u32 farm = 0;                       // bit k: the source of the k-th newest match starts before rbuf[0]
 	u32 err = 0;                        // 1: the index and the stream disagree, 2: distance beyond the output start
 	u32 pos = s_bit;
 	if (active) {
@@ -135,7 +135,7 @@ OTZ_DEV u32 otz_place_items(otz_apply_lds &L, bool active, u32 s_bit, u32 e_bit,
 				k2 = otz_alignbit (k2, k1, 16);
 				k1 = otz_alignbit (k1, k0, 16);
 				k0 = (k0 << 16) | ri;
-				farm = (farm << 1) | (dist >= ri + val ? 1u : 0u);
+				farm = (farm << 1) | (dist > ri ? 1u : 0u);
 				nm += 1u;
 				ri += val;
 				pos += used + dl + dxb;
@@ -157,8 +157,8 @@ OTZ_DEV u32 otz_place_items(otz_apply_lds &L, bool active, u32 s_bit, u32 e_bit,
 		L.dbg[3] = e_bit;
 		otz_set_status (L, OZG_ST_INTERNAL);
 	}
-	// two lists: the matches that (also) read the buffer in stream order from list[0] on, the ones that read only
-	// the entry's output in global memory from the end of the list's room downwards (in any order)
+	// two lists: the matches whose source lies in the buffer in stream order from list[0] on, the ones whose source
+	// starts in the entry's output in global memory from the end of the list's room downwards (in any order)
 	const u32 nf = otz_popc (farm), nn = nm - nf;
 	u32 total;
 	const u32 incl = otz_block_scan_incl (nn | (nf << 16), L.scan, &total); // (two barriers: every stage read is done)
@@ -178,128 +178,68 @@ OTZ_DEV u32 otz_place_items(otz_apply_lds &L, bool active, u32 s_bit, u32 e_bit,
 	return total & 0xFFFFu;
 }
 
-// The matches whose source lies wholly before rbuf[0]: those bytes were final, and in global memory, before the
-// round began, so these copies depend on nothing and are made first, all of a lane's loads in flight together --
-// one trip to the L2 per round instead of one inside every iteration of the resolution loop below.
+// One step of a copy: n <= 16 bytes (lo: the first eight, hi: the rest) to buffer position o, then their final bits.
+// (An unaligned 2-byte store is cheap, an unaligned 4-byte store costs three of them.)
+OTZ_DEV void otz_a_put(otz_apply_lds &L, u32 o, u64 lo, u64 hi, u32 n) {
+	u8 *dst = &L.rbuf[o];
+	u64 v = lo;
+	if (n & 16u) {
+		otz_st64u (dst, lo);
+		otz_st64u (dst + 8, hi);
+	} else {
+		if (n & 8u) {
+			otz_st64u (dst, lo);
+			v = hi;
+			dst += 8;
+		}
+		if (n & 4u) {
+			otz_st16u (dst, (u16)v);
+			otz_st16u (dst + 2, (u16) (v >> 16));
+			v >>= 32;
+			dst += 4;
+		}
+		if (n & 2u) {
+			otz_st16u (dst, (u16)v);
+			v >>= 16;
+			dst += 2;
+		}
+		if (n & 1u) {
+			*dst = (u8)v;
+		}
+	}
+	otz_order_stores ();
+	const u64 mask = (((u64)1 << n) - 1u) << (o & 31u);
+	otz_lds_or (&L.fin[o >> 5], (u32)mask);
+	if ((u32) (mask >> 32)) {
+		otz_lds_or (&L.fin[(o >> 5) + 1u], (u32) (mask >> 32));
+	}
+}
+
+// The matches whose source STARTS before rbuf[0], in the entry's output in global memory.  Such a source ends
+// before the round does (the buffer keeps OTZ_A_WIN >= 258 bytes in front of the round, or the entry's whole
+// output so far), so every byte of it was final before the round began: these copies depend on nothing and are
+// made first, all of a lane's loads in flight together -- one trip to the L2 per round instead of one inside
+// every iteration of the resolution loop below.  (The part of a source that lies in the buffer is read there.)
 OTZ_DEV void otz_far_copies(otz_apply_lds &L, const otz_job &J, u32 p0, const u16 *list, u32 n_far) {
 	for (u32 m = otz_tid (); m < n_far; m += OTZ_NT) {
 		u32 o = list[OTZ_A_LIST_CAP - 1u - m];
 		const u64 dw = otz_ld64u (&L.rbuf[o & ~3u]);
 		const u32 cd = otz_alignbyte ((u32) (dw >> 32), (u32)dw, o) & 0xFFFFFFu;
 		u32 pend = (cd >> 15) + 3u;
-		const u8 *g = J.out + (p0 + o - ((cd & 0x7FFFu) + 1u)); // (>= J.out: the distance was checked against the position)
+		int si = (int)o - (int) ((cd & 0x7FFFu) + 1u); // (p0 + si >= 0: the distance was checked against the position)
 		while (pend != 0) {
-			const u32 n = pend < 16u ? pend : 16u;
-			const u32 *gp = reinterpret_cast<const u32 *> ((uintptr_t)g & ~(uintptr_t)3);
-			const u32 q = (u32) (uintptr_t)g & 3u;
-			const u32 span = q + n; // 1..19: only the words that hold bytes of the source (they lie inside the entry's output)
-			const u32 s0 = gp[0];
-			const u32 s1 = span > 4u ? gp[1] : 0u;
-			const u32 s2 = span > 8u ? gp[2] : 0u;
-			const u32 s3 = span > 12u ? gp[3] : 0u;
-			const u32 s4 = span > 16u ? gp[4] : 0u;
-			const u64 lo = otz_alignbyte (s1, s0, q) | ((u64)otz_alignbyte (s2, s1, q) << 32);
-			const u64 hi = otz_alignbyte (s3, s2, q) | ((u64)otz_alignbyte (s4, s3, q) << 32);
-			u8 *dst = &L.rbuf[o];
-			u64 v = lo;
-			if (n & 16u) {
-				otz_st64u (dst, lo);
-				otz_st64u (dst + 8, hi);
-			} else {
-				if (n & 8u) {
-					otz_st64u (dst, lo);
-					v = hi;
-					dst += 8;
-				}
-				if (n & 4u) {
-					otz_st16u (dst, (u16)v);
-					otz_st16u (dst + 2, (u16) (v >> 16));
-					v >>= 32;
-					dst += 4;
-				}
-				if (n & 2u) {
-					otz_st16u (dst, (u16)v);
-					v >>= 16;
-					dst += 2;
-				}
-				if (n & 1u) {
-					*dst = (u8)v;
-				}
-			}
-			otz_order_stores ();
-			const u64 mask = (((u64)1 << n) - 1u) << (o & 31u);
-			otz_lds_or (&L.fin[o >> 5], (u32)mask);
-			if ((u32) (mask >> 32)) {
-				otz_lds_or (&L.fin[(o >> 5) + 1u], (u32) (mask >> 32));
-			}
-			o += n;
-			g += n;
-			pend -= n;
-		}
-	}
-}
-
-// ---------------------------------------------------------------- LZ77 resolution
-//
-// The copies, in stream order: lane j takes matches j, j + OTZ_NT, ... of the list, one after
-// the other, and fetches the next as soon as one is done (no lane waits for the slowest of a
-// batch).  OTZ_NT consecutive matches span a few KB of output, so most sources lie in
-// stretches that are already final; the others wait for exactly the bytes they need: each
-// step copies up to 16 bytes once the per-byte final bits of THOSE source bytes are set (two
-// bitmap words and the 16 source bytes in one LDS round trip), then sets the bits of what it
-// wrote.  A source before rbuf[0] is read from the entry's output in global memory: those
-// bytes were final, and stored, before the round began.  The earliest unresolved match of the
-// round is some lane's current one and never waits, so the loop cannot stall; it is closed by
-// ballots (a convergent exit keeps the waiting lanes and the lanes they wait for in the same
-// loop -- see otz_resolve in otz_inflate.h).
-// An overlapping match (distance < 16) copies one period, then two, four, ...
-OTZ_DEV void otz_resolve_list(otz_apply_lds &L, const otz_job &J, u32 p0, const u16 *list, u32 n_matches) {
-	u32 m = otz_tid (); // this lane's next match
-	u32 pend = 0, pdist = 1, o = 0;
-	int si = 0; // buffer position of the source; negative: before the buffer
-	u32 spins = 0;
-#ifdef OTZ_RES_PROF // diagnostics: where an iteration's time goes (every wait drained at the marks: slots 1, 5, 6, 9)
-	u64 rp0 = 0, rp1 = 0, rp2 = 0, rp3 = 0, rpt = otz_cycles ();
-#define OTZ_RP(acc) do { asm volatile ("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const u64 _t = otz_cycles (); acc += _t - rpt; rpt = _t; } while (0)
-#else
-#define OTZ_RP(acc) do { } while (0)
-#endif
-	for (;;) {
-		OTZ_COUNT (L, J, OTZ_P_B_ITERS, 1);
-		if (pend == 0 && m < n_matches) {
-			// ---- next match of this lane: its parked descriptor
-			o = list[m];
-			const u64 dw = otz_ld64u (&L.rbuf[o & ~3u]);
-			const u32 cd = otz_alignbyte ((u32) (dw >> 32), (u32)dw, o) & 0xFFFFFFu;
-			pdist = (cd & 0x7FFFu) + 1u;
-			pend = (cd >> 15) + 3u;
-			si = (int)o - (int)pdist;
-			m += OTZ_A_RES_LANES;
-		}
-		OTZ_RP (rp0);
-		// ---- one step: up to 16 bytes that neither overlap their own source nor straddle rbuf[0]
-		u32 n = pend < 16u ? pend : 16u;
-		n = n < pdist ? n : pdist;
-		const bool far = si < 0;
-		if (far) {
-			n = n < (u32)-si ? n : (u32)-si;
-		}
-		const u32 a = far ? 0u : (u32)si;
-		const u32 b = far ? 0u : (u32)si + n;
-		const u64 have = otz_ld64u (&L.fin[a >> 5]); // (b - a <= 16 bits: words a/32 and a/32 + 1 hold them)
-		otz_order_loads (); // "flag, then data": the source bytes are read after the bits that declare them final
-		const u64 need = b > a ? (((u64)1 << (b - a)) - 1u) << (a & 31u) : 0u;
-		const bool go = pend != 0 && (have & need) == need;
-		OTZ_RP (rp1);
-		if (go) {
-			// the source bytes: dword-aligned reads, then a byte funnel shift (LDS reads past the bytes
-			// used land in the buffer's slack and are ignored)
-			u32 s0, s1, s2, s3 = 0, s4 = 0;
+			u32 n = pend < 16u ? pend : 16u;
+			const bool far = si < 0;
 			if (far) {
-				const u8 *g = J.out + (p0 + (u32)si); // (p0 + si >= 0: the distance was checked against the position)
+				n = n < (u32)-si ? n : (u32)-si; // (a step does not straddle rbuf[0])
+			}
+			u32 s0, s1, s2, s3, s4;
+			u32 q;
+			if (far) {
+				const u8 *g = J.out + (p0 + (u32)si);
 				const u32 *gp = reinterpret_cast<const u32 *> ((uintptr_t)g & ~(uintptr_t)3);
-				// only the words that hold bytes of the source: those lie before p0, inside the entry's output
-				const u32 span = ((u32) (uintptr_t)g & 3u) + n; // 1..19
+				q = (u32) (uintptr_t)g & 3u;
+				const u32 span = q + n; // 1..19: only the words that hold bytes of the source (they lie inside the entry's output)
 				s0 = gp[0];
 				s1 = span > 4u ? gp[1] : 0u;
 				s2 = span > 8u ? gp[2] : 0u;
@@ -307,69 +247,106 @@ OTZ_DEV void otz_resolve_list(otz_apply_lds &L, const otz_job &J, u32 p0, const 
 				s4 = span > 16u ? gp[4] : 0u;
 			} else {
 				const u32 *sp = reinterpret_cast<const u32 *> (&L.rbuf[(u32)si & ~3u]);
-				const u64 s01 = otz_ld64u (sp);
-				s0 = (u32)s01;
-				s1 = (u32) (s01 >> 32);
+				q = (u32)si & 3u;
+				s0 = sp[0];
+				s1 = sp[1];
 				s2 = sp[2];
-				if (n > 8u) {
-					const u64 s34 = otz_ld64u (sp + 3);
-					s3 = (u32)s34;
-					s4 = (u32) (s34 >> 32);
-				}
+				s3 = sp[3];
+				s4 = sp[4];
 			}
-			const u32 q = far ? (u32) ((uintptr_t) (J.out + (p0 + (u32)si)) & 3u) : (u32)si & 3u;
 			const u64 lo = otz_alignbyte (s1, s0, q) | ((u64)otz_alignbyte (s2, s1, q) << 32);
 			const u64 hi = otz_alignbyte (s3, s2, q) | ((u64)otz_alignbyte (s4, s3, q) << 32);
-			// an unaligned 2-byte store is cheap, an unaligned 4-byte store costs three of them
-			u8 *dst = &L.rbuf[o];
-			u64 v = lo;
-			if (n & 16u) {
-				otz_st64u (dst, lo);
-				otz_st64u (dst + 8, hi);
-			} else {
-				if (n & 8u) {
-					otz_st64u (dst, lo);
-					v = hi;
-					dst += 8;
-				}
-				if (n & 4u) {
-					otz_st16u (dst, (u16)v);
-					otz_st16u (dst + 2, (u16) (v >> 16));
-					v >>= 32;
-					dst += 4;
-				}
-				if (n & 2u) {
-					otz_st16u (dst, (u16)v);
-					v >>= 16;
-					dst += 2;
-				}
-				if (n & 1u) {
-					*dst = (u8)v;
-				}
+			otz_a_put (L, o, lo, hi, n);
+			o += n;
+			si += (int)n;
+			pend -= n;
+		}
+	}
+}
+
+// ---------------------------------------------------------------- LZ77 resolution
+//
+// The copies whose source lies in the buffer, in stream order: lane j takes matches j, j + OTZ_A_RES_LANES, ... of
+// the list, one after the other, and takes the next as soon as one is done (no lane waits for the slowest of a
+// batch).  Consecutive matches span a few KB of output, so most sources lie in stretches that are already final;
+// the others wait for exactly the bytes they need: each step copies up to 16 bytes once the per-byte final bits
+// of THOSE source bytes are set (two bitmap words and the 16 source bytes in one LDS round trip), then sets the
+// bits of what it wrote.  The earliest unresolved match of the round is some lane's current one and never waits,
+// so the loop cannot stall; it is closed by ballots (a convergent exit keeps the waiting lanes and the lanes they
+// wait for in the same loop -- see otz_resolve in otz_inflate.h).
+// The loop runs as many iterations as the round's longest chain of matches copying from matches, so an iteration
+// is kept short: a lane's NEXT match -- its place in the list two ahead, its parked descriptor one ahead -- is
+// fetched while the current one is copied, so that a step waits for one LDS round trip, not three.
+// An overlapping match (distance < 16) copies one period, then two, four, ...
+#define OTZ_A_NOMATCH 0u // (no match is written to buffer position 0: a match needs bytes in front of it)
+OTZ_DEV void otz_resolve_list(otz_apply_lds &L, const otz_job &J, const u16 *list, u32 n_matches) {
+	u32 m = otz_tid (); // list index of the match after next
+	u32 on1 = OTZ_A_NOMATCH, on2 = OTZ_A_NOMATCH; // destinations of the next match and of the one after
+	if (m < n_matches) {
+		on1 = list[m];
+		m += OTZ_A_RES_LANES;
+	}
+	if (m < n_matches) {
+		on2 = list[m];
+	}
+	u64 dn1 = otz_ld64u (&L.rbuf[on1 & ~3u]); // the words that hold the next match's parked descriptor
+	u32 pend = 0, pdist = 1, o = 0, si = 0;
+	u32 spins = 0;
+	for (;;) {
+		OTZ_COUNT (L, J, OTZ_P_B_ITERS, 1);
+		if (pend == 0 && on1 != OTZ_A_NOMATCH) {
+			// ---- next match of this lane: it is in registers
+			const u32 cd = otz_alignbyte ((u32) (dn1 >> 32), (u32)dn1, on1) & 0xFFFFFFu;
+			o = on1;
+			pdist = (cd & 0x7FFFu) + 1u;
+			pend = (cd >> 15) + 3u;
+			si = o - pdist; // (>= 0: the matches that reach in front of the buffer are otz_far_copies')
+			on1 = on2;
+			m += OTZ_A_RES_LANES;
+		}
+		// ---- ask for what the next take needs, every iteration and whether or not it changed: loads that are
+		// always issued here are in flight while this step's reads are, and their registers are the loop's own
+		// (a load inside the branch above is waited for on the spot: its value has to be merged with the old one)
+		const u32 on2_next = list[m < n_matches ? m : 0u];
+		const u64 dn1_next = otz_ld64u (&L.rbuf[on1 & ~3u]);
+		// ---- one step: up to 16 bytes that do not overlap their own source
+		u32 n = pend < 16u ? pend : 16u;
+		n = n < pdist ? n : pdist;
+		const u64 have = otz_ld64u (&L.fin[si >> 5]); // (n <= 16 bits: words si/32 and si/32 + 1 hold them)
+		otz_order_loads (); // "flag, then data": the source bytes are read after the bits that declare them final
+		const u64 need = (((u64)1 << n) - 1u) << (si & 31u);
+		const bool go = pend != 0 && (have & need) == need;
+		if (go) {
+			// the source bytes: dword-aligned reads, then a byte funnel shift (LDS reads past the bytes
+			// used land in the buffer's slack and are ignored)
+			const u32 *sp = reinterpret_cast<const u32 *> (&L.rbuf[si & ~3u]);
+			const u64 s01 = otz_ld64u (sp);
+			const u32 s0 = (u32)s01, s1 = (u32) (s01 >> 32), s2 = sp[2];
+			u32 s3 = 0, s4 = 0;
+			if (n > 8u) {
+				const u64 s34 = otz_ld64u (sp + 3);
+				s3 = (u32)s34;
+				s4 = (u32) (s34 >> 32);
 			}
-			otz_order_stores ();
-			const u64 mask = (((u64)1 << n) - 1u) << (o & 31u);
-			otz_lds_or (&L.fin[o >> 5], (u32)mask);
-			if ((u32) (mask >> 32)) {
-				otz_lds_or (&L.fin[(o >> 5) + 1u], (u32) (mask >> 32));
-			}
+			const u32 q = si & 3u;
+			const u64 lo = otz_alignbyte (s1, s0, q) | ((u64)otz_alignbyte (s2, s1, q) << 32);
+			const u64 hi = otz_alignbyte (s3, s2, q) | ((u64)otz_alignbyte (s4, s3, q) << 32);
+			otz_a_put (L, o, lo, hi, n);
 			o += n;
 			pend -= n;
 			// a whole period written: same source, twice the reach; otherwise the source slides along
 			const bool dbl = n == pdist && pdist < 16u;
-			si += dbl ? 0 : (int)n;
+			si += dbl ? 0u : n;
 			pdist += dbl ? n : 0u;
 		}
-		OTZ_RP (rp2);
+		on2 = m < n_matches ? on2_next : OTZ_A_NOMATCH;
+		dn1 = dn1_next;
 		if (J.prof) { // diagnostics: lanes that copied / lanes that had a match in hand, this iteration (wavefront 0)
 			const u32 ng = otz_popc64 (otz_ballot (go)), np = otz_popc64 (otz_ballot (go || pend != 0));
 			OTZ_COUNT (L, J, 11, ng);
 			OTZ_COUNT (L, J, 0, np);
-			const u32 nf = otz_popc64 (otz_ballot (go && far));
-			OTZ_COUNT (L, J, 4, nf);
-			OTZ_COUNT (L, J, 5, nf ? 1u : 0u);
 		}
-		if (otz_ballot (pend != 0 || m < n_matches) == 0) {
+		if (otz_ballot (pend != 0 || on1 != OTZ_A_NOMATCH) == 0) {
 			break;
 		}
 		if (otz_ballot (go) == 0) { // every live lane of this wavefront waits on another wavefront
@@ -381,21 +358,14 @@ OTZ_DEV void otz_resolve_list(otz_apply_lds &L, const otz_job &J, u32 p0, const 
 				if (spins > OTZ_SPIN_LIMIT) {
 					L.dbg[0] = 3; // waited too long for source bytes
 					L.dbg[1] = otz_tid ();
-					L.dbg[2] = p0 + o;
+					L.dbg[2] = o;
 					L.dbg[3] = pdist | (pend << 16);
 					otz_set_status (L, OZG_ST_INTERNAL);
 					break;
 				}
 			}
 		}
-		OTZ_RP (rp3);
 	}
-#ifdef OTZ_RES_PROF
-	OTZ_COUNT (L, J, 1, rp0);
-	OTZ_COUNT (L, J, 5, rp1);
-	OTZ_COUNT (L, J, 6, rp2);
-	OTZ_COUNT (L, J, 9, rp3);
-#endif
 }
 
 // ---------------------------------------------------------------- rounds
@@ -634,7 +604,7 @@ OTZ_DEV void otz_apply_entry(otz_apply_lds &L, const otz_job &J, const otz_ix_he
 			otz_set_priority_high (); // (the resolution loop goes first, the bulk phases of the other workgroups fill the gaps)
 #endif
 			if (OTZ_A_RES_LANES == OTZ_NT || tid < OTZ_A_RES_LANES) {
-				otz_resolve_list (L, J, P.p0, list, n_matches);
+				otz_resolve_list (L, J, list, n_matches);
 			}
 #if OTZ_A_RES_PRIO
 			otz_set_priority_normal ();
