@@ -335,6 +335,7 @@ static int ozs_decode(z_stream *strm) {
 	const int real_brotli = st->method == OZG_METHOD_BROTLI && in_len >= 1 && !(in_len >= 4 && memcmp (in, "BROT", 4) == 0);
 	const int real_lzma = st->method == OZG_METHOD_LZMA && in_len >= 14 && in[2] == 5 && in[3] == 0;
 	const int real_lzfse = st->method == OZG_METHOD_LZFSE && in_len >= 4 && memcmp (in, "bvx", 3) == 0; /* (its end block says where it ends) */
+	int real_needs_room = 0;
 	if ((real_brotli || real_lzma || real_lzfse) && st->out_made == 0) {
 		ozg_entry e;
 		memset (&e, 0, sizeof (e));
@@ -358,13 +359,12 @@ static int ozs_decode(z_stream *strm) {
 			return Z_STREAM_END;
 		}
 		free (out);
-		if (rc == OZG_OK && r.status == OZG_ST_SIZE) {
-			/* a stream of the real format, valid as far as the room went: the caller's buffer is too small.
-			 * Nothing is consumed or written; a caller that grows its buffer and calls again (the reference's
-			 * CLI does: ref src/main.c:612-650) gets the stream then.  (Falling through to the reference's
-			 * container decoder would answer Z_DATA_ERROR for a valid stream.) */
-			return Z_BUF_ERROR;
-		}
+		/* a stream of the real format that was valid as far as the room went: the caller's buffer is too small.  The
+		 * reference's container reader has the first word (it accepts things by its own, looser rules); what it
+		 * turns down is then answered Z_BUF_ERROR with nothing consumed or written, so that a caller that grows its
+		 * buffer and calls again (the reference's CLI does: ref src/main.c:612-650) gets the stream then -- not the
+		 * Z_DATA_ERROR the container reader has for a valid stream of the real format */
+		real_needs_room = rc == OZG_OK && r.status == OZG_ST_SIZE;
 	}
 	if (st->method != OZG_METHOD_DEFLATE && st->method != OZG_METHOD_LZMA) {
 		long long plen = st->method == OZG_METHOD_ZSTD ? ozs_zstd_content_size (in, (uInt)in_len) : -1;
@@ -470,6 +470,9 @@ static int ozs_decode(z_stream *strm) {
 		break;
 	}
 	free (out);
+	if (real_needs_room && ret != Z_STREAM_END && ret != Z_OK) {
+		ret = Z_BUF_ERROR;
+	}
 	return ret;
 }
 
