@@ -134,6 +134,8 @@ OTZ_DEV u32 otz_k1_hbits(const otz_k1_lds &L, u32 p) { // 32 staged bits from bi
 	return otz_alignbit (L.h.hdr_w[w + 1u], L.h.hdr_w[w], p & 31u);
 }
 
+// (The block prologue below synchronises LDS traffic only -- otz_wave_sync_lds: the LDS executes a wavefront's
+// instructions in order -- so that it never waits for the stores of the index that are still on their way.)
 // BFINAL/BTYPE and HLIT/HDIST/HCLEN of a dynamic block plus the 7-bit table of the
 // code-length code (ref deflate-dec.inc.c:613-627, :122-156); same construction as
 // otz_parse_header_par, one wavefront.  *cl_ok = 0 for an over-subscribed code-length code.
@@ -168,7 +170,7 @@ OTZ_DEV otz_hdr otz_k1_parse_header(otz_k1_lds &L, u32 p, u64 avail, u32 *cl_ok)
 	const u32 lane = otz_opaque (otz_lane ()); // (opaque: nothing derived from it is computed once at the top of the kernel and kept, spilled, across everything else)
 	L.h.cl_lut[lane] = 0;
 	L.h.cl_lut[lane + 64u] = 0;
-	otz_wave_sync ();
+	otz_wave_sync_lds ();
 	const u64 inv_lo = 3ull | (17ull << 5) | (15ull << 10) | (13ull << 15) | (11ull << 20) | (9ull << 25) | (7ull << 30) | (5ull << 35) |
 		(4ull << 40) | (6ull << 45) | (8ull << 50) | (10ull << 55);
 	const u64 inv_hi = 12ull | (14ull << 5) | (16ull << 10) | (18ull << 15) | (0ull << 20) | (1ull << 25) | (2ull << 30);
@@ -198,7 +200,7 @@ OTZ_DEV otz_hdr otz_k1_parse_header(otz_k1_lds &L, u32 p, u64 avail, u32 *cl_ok)
 		}
 	}
 	*cl_ok = kraft <= 128u ? 1u : 0u;
-	otz_wave_sync ();
+	otz_wave_sync_lds ();
 	return H;
 }
 
@@ -214,7 +216,7 @@ OTZ_DEV int otz_k1_parse_lengths(otz_k1_lds &L, u32 p, u64 avail, u32 n, u32 *bi
 	for (u32 i = lane; i < OTZ_IX_LENS; i += 64u) {
 		L.h.ll[i] = 0;
 	}
-	otz_wave_sync ();
+	otz_wave_sync_lds ();
 	u32 idx = 0, pos = 0;
 	while (idx < n) {
 		const u32 at = pos + lane;
@@ -258,7 +260,7 @@ OTZ_DEV int otz_k1_parse_lengths(otz_k1_lds &L, u32 p, u64 avail, u32 n, u32 *bi
 		idx = got;
 		pos += cur;
 	}
-	otz_wave_sync ();
+	otz_wave_sync_lds ();
 	u32 carry = 0xFFu;
 	for (u32 base = 0; base < n; base += 64u) {
 		const u32 i = base + lane;
@@ -268,13 +270,13 @@ OTZ_DEV int otz_k1_parse_lengths(otz_k1_lds &L, u32 p, u64 avail, u32 n, u32 *bi
 		const u32 srcl = mm ? 63u - otz_clz64 (mm) : 0u;
 		u32 val = otz_shfl (v & 0x1Fu, srcl);
 		val = mm ? val : carry;
-		otz_wave_sync ();
+		otz_wave_sync_lds ();
 		if (i < n) {
 			L.h.ll[i] = (u8)val;
 		}
 		carry = otz_readlane (val, 63u);
 	}
-	otz_wave_sync ();
+	otz_wave_sync_lds ();
 	*bits_used = pos;
 	return 0;
 }
@@ -369,7 +371,7 @@ OTZ_DEV int otz_k1_build_tables(otz_k1_lds &L, u32 hlit, u32 hdist) {
 		if (otz_readlane (first + cnt, 15u) > (1u << 15)) {
 			st = OZG_ST_DATA;
 		}
-		otz_wave_sync ();
+		otz_wave_sync_lds ();
 		// short codes: the symbol writes every root slot that starts with its code
 		for (u32 base = 0; base < nsym; base += 64u) {
 			const u32 sym = base + lane;
@@ -412,7 +414,7 @@ OTZ_DEV int otz_k1_build_tables(otz_k1_lds &L, u32 hlit, u32 hdist) {
 				}
 			}
 		}
-		otz_wave_sync ();
+		otz_wave_sync_lds ();
 		// sub-table placement: running sum over the root slots
 		u32 total = 0;
 		for (u32 base = 0; base < rsz; base += 64u) {
@@ -430,7 +432,7 @@ OTZ_DEV int otz_k1_build_tables(otz_k1_lds &L, u32 hlit, u32 hdist) {
 		if (total > cap - rsz) {
 			st = st ? st : OTZ_IX_OVERFLOW;
 		}
-		otz_wave_sync ();
+		otz_wave_sync_lds ();
 		if (st == 0) {
 			for (u32 base = 0; base < nsym; base += 64u) {
 				const u32 sym = base + lane;
@@ -447,7 +449,7 @@ OTZ_DEV int otz_k1_build_tables(otz_k1_lds &L, u32 hlit, u32 hdist) {
 				}
 			}
 		}
-		otz_wave_sync ();
+		otz_wave_sync_lds ();
 	}
 	return st;
 }

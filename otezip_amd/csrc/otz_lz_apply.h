@@ -397,16 +397,20 @@ OTZ_DEV void otz_resolve_list(otz_apply_lds &L, const otz_job &J, const u16 *lis
 		}
 		on2 = m < n_matches ? on2_next : OTZ_A_NOMATCH;
 		dn1 = dn1_next;
+#ifdef OTZ_A_RES_STATS
 		if (J.prof) { // diagnostics: lanes that copied / lanes that had a match in hand, this iteration (wavefront 0)
 			const u32 ng = otz_popc64 (otz_ballot (go)), np = otz_popc64 (otz_ballot (go || pend != 0));
 			OTZ_COUNT (L, J, 11, ng);
 			OTZ_COUNT (L, J, 0, np);
 		}
+#endif
 		if (otz_ballot (pend != 0 || on1 != OTZ_A_NOMATCH) == 0) {
 			break;
 		}
 		if (otz_ballot (go) == 0) { // every live lane of this wavefront waits on another wavefront
+#ifndef OTZ_A_RES_NOSLEEP
 			otz_backoff ();
+#endif
 			if ((++spins & 63u) == 0) {
 				if (otz_get_status (L) != 0) {
 					break;

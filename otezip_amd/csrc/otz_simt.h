@@ -106,7 +106,10 @@ OTZ_DEV void otz_backoff() { __builtin_amdgcn_s_sleep (2); }
 // Issue priority of this wavefront (0 = default .. 3): raised around dependency-bound phases
 // so that the few wavefronts on the critical path are not queued behind the bulk work of
 // the other workgroup on the CU.
-OTZ_DEV void otz_set_priority_high() { __builtin_amdgcn_s_setprio (2); }
+#ifndef OTZ_PRIO_HIGH
+#define OTZ_PRIO_HIGH 2
+#endif
+OTZ_DEV void otz_set_priority_high() { __builtin_amdgcn_s_setprio (OTZ_PRIO_HIGH); }
 OTZ_DEV void otz_set_priority_normal() { __builtin_amdgcn_s_setprio (0); }
 
 // shader clock, for the diagnostic phase counters only
