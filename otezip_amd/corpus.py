@@ -152,10 +152,18 @@ def build_archive(n, size, methods=(8,), workers=None, first=0):
     return _cached(tag, lambda: _build_archive(n, size, methods, workers, first), 1000, n)
 
 
+def _default_workers():
+    """OTEZIP_CORPUS_NO_FORK=1 (what the tools set before a rocprofv3 pass): a corpus that is not in the cache is
+    generated in this process, slowly, instead of by a forked pool -- a process the profiler has GPU-initialised must not fork."""
+    if os.environ.get("OTEZIP_CORPUS_NO_FORK", "0") not in ("", "0"):
+        return 1
+    return min(mp.cpu_count(), 16)
+
+
 def _build_archive(n, size, methods, workers, first):
     jobs = [(first + i, size, methods[i % len(methods)]) for i in range(n)]
     if workers is None:
-        workers = min(mp.cpu_count(), 16)
+        workers = _default_workers()
     if workers > 1 and n >= 64:
         with mp.get_context("fork").Pool(workers) as pool:
             made = pool.map(_make_one, jobs, chunksize=max(1, n // (workers * 8)))
@@ -201,7 +209,7 @@ def text_buffers(n, size, first=0, workers=None):
 def _text_buffers(n, size, first, workers):
     jobs = [(first + i, size) for i in range(n)]
     if workers is None:
-        workers = min(mp.cpu_count(), 16)
+        workers = _default_workers()
     if workers > 1 and n >= 64:
         with mp.get_context("fork").Pool(workers) as pool:
             return pool.map(_text_one, jobs, chunksize=max(1, n // (workers * 8)))

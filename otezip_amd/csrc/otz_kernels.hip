@@ -285,6 +285,37 @@ otz_lzfse_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *r
 	}
 }
 
+// How many entries of a batch each of the real-format kernels would take (the same tests those kernels make):
+// counts[0..3] = Zstandard, LZMA1, Brotli, LZFSE.  For batches whose payloads are only on the device, where the
+// host cannot look: a kernel none of whose entries is in the batch is not launched and gets no scratch, and the
+// scratch of the others is sized by what the batch holds, not by its number of entries.
+extern "C" __global__ void __launch_bounds__ (256)
+otz_sniff_kernel(const u8 *src, const ozg_entry *entries, u32 n, u64 src_len, u64 dst_len, ozg_limits lim, u32 *counts) {
+	const u32 i = blockIdx.x * 256u + threadIdx.x;
+	u32 which = 4u;
+	if (i < n) {
+		const ozg_entry e = entries[i];
+		if (otz_entry_in_bounds (e, src_len, dst_len) && !otz_zipbomb (e, lim)) {
+			const u8 *p = src + e.src_off;
+			if (e.method == OZG_METHOD_ZSTD && otz_zs_is_candidate (p, e.comp_size)) {
+				which = 0u;
+			} else if (e.method == OZG_METHOD_LZMA && otz_lzma_is_candidate (p, e.comp_size)) {
+				which = 1u;
+			} else if (e.method == OZG_METHOD_BROTLI && otz_brotli_is_candidate (p, e.comp_size)) {
+				which = 2u;
+			} else if (e.method == OZG_METHOD_LZFSE && otz_lzfse_is_candidate (p, e.comp_size)) {
+				which = 3u;
+			}
+		}
+	}
+	for (u32 k = 0; k < 4u; k++) { // (one atomic per wavefront and format)
+		const u64 m = otz_ballot (which == k);
+		if (m != 0 && otz_lane () == otz_ctz64 (m)) {
+			atomicAdd (&counts[k], otz_popc64 (m));
+		}
+	}
+}
+
 // CRC-32 of the entries otz_zstd_kernel / otz_lzma_kernel / otz_brotli_kernel / otz_lzfse_kernel decoded (ref src/lib/otezip.c:667-679)
 extern "C" __global__ void __launch_bounds__ (256)
 otz_zstd_crc_kernel(u8 *dst, const ozg_entry *entries, ozg_result *results, u32 n, const u8 *route) {
@@ -528,6 +559,7 @@ otz_pack_copy_kernel(const u8 *dst, const ozg_enc_entry *entries, const ozg_enc_
 namespace {
 
 constexpr int MAX_DEV = 16;
+#define OTZ_BATCH_HOST_SNIFFED 0x80000000u // (internal batch flag: the host has looked at the payloads' first bytes; see check_entries)
 constexpr int N_SLOTS = 8; // asynchronous staged batches in flight per device (a full table is back-pressure for the caller: OZG_E_NOMEM)
 
 std::mutex g_mu; // contexts, their buffers and slots
@@ -868,15 +900,41 @@ int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, 
 	}
 	if (!(batch_flags & OZG_BATCH_ONLY_DEFLATE)) {
 		const u8 *route = nullptr;
-		const bool want_zs = !(batch_flags & OZG_BATCH_NO_ZSTD), want_lz = !(batch_flags & OZG_BATCH_NO_LZMA), want_br = !(batch_flags & OZG_BATCH_NO_BROTLI);
-		const bool want_lf = !(batch_flags & OZG_BATCH_NO_LZFSE);
+		bool want_zs = !(batch_flags & OZG_BATCH_NO_ZSTD), want_lz = !(batch_flags & OZG_BATCH_NO_LZMA), want_br = !(batch_flags & OZG_BATCH_NO_BROTLI);
+		bool want_lf = !(batch_flags & OZG_BATCH_NO_LZFSE);
+		u32 have[4] = { n, n, n, n }; // entries each real-format kernel would take, at most
+		if ((want_zs || want_lz || want_br || want_lf) && !(batch_flags & OTZ_BATCH_HOST_SNIFFED)) {
+			// What the batch holds is counted where the payloads are (a caller that staged them from host memory has
+			// said so through batch_flags; for the rest this costs one small kernel and 16 bytes back): a format
+			// none of whose streams is in the batch gets no kernel and no scratch, the others scratch for what there is.
+			workspace &ws = C.ws;
+			if (!ws.zs_cursor) {
+				OZG_HIP (hipMalloc ((void **)&ws.zs_cursor, 256));
+				OZG_HIP (hipMalloc ((void **)&ws.lz_cursor, 256));
+				OZG_HIP (hipMalloc ((void **)&ws.br_cursor, 256));
+			}
+			if (ws.busy) {
+				OZG_HIP (hipStreamWaitEvent (s, ws.done, 0)); // (the counters are shared between streams)
+			}
+			OZG_HIP (hipMemsetAsync (ws.zs_cursor + 16, 0, 16, s));
+			hipLaunchKernelGGL (otz_sniff_kernel, dim3 ((n + 255u) / 256u), dim3 (256), 0, s, (const u8 *)d_src, d_entries, n, (u64)src_len, (u64)dst_len, g_limits,
+				ws.zs_cursor + 16);
+			OZG_HIP (hipGetLastError ());
+			OZG_HIP (hipMemcpyAsync (have, ws.zs_cursor + 16, sizeof (have), hipMemcpyDeviceToHost, s));
+			OZG_HIP (hipStreamSynchronize (s));
+			want_zs = want_zs && have[0] != 0;
+			want_lz = want_lz && have[1] != 0;
+			want_br = want_br && have[2] != 0;
+			want_lf = want_lf && have[3] != 0;
+		}
 		if (want_zs || want_lz || want_br || want_lf) {
 			// methods 93 and 14: the real formats first (the rest of the batch, and what turns out not to
 			// be one of them, is the copy kernel's)
 			workspace &ws = C.ws;
-			const u32 grid = n < C.zs_grid ? n : C.zs_grid;
-			const u32 lz_threads = ((n < 32768u ? n : 32768u) + 63u) & ~63u;
-			const u32 br_threads = ((n < 16384u ? n : 16384u) + 63u) & ~63u;
+			const u32 grid = have[0] < C.zs_grid ? have[0] : C.zs_grid;
+			const u32 lz_threads = ((have[1] < 32768u ? have[1] : 32768u) + 63u) & ~63u;
+			const u32 br_n = have[2] > have[3] ? have[2] : have[3];
+			const u32 br_threads = ((br_n < 16384u ? br_n : 16384u) + 63u) & ~63u;
 			if (!ws.done) {
 				OZG_HIP (hipEventCreateWithFlags (&ws.done, hipEventDisableTiming));
 			}
@@ -1012,7 +1070,7 @@ int check_entries(const ozg_entry *entries, uint32_t n, uint64_t src_len, uint64
 			f &= ~OZG_BATCH_NO_LZFSE;
 		}
 	}
-	*flags = f;
+	*flags = f | (h_src ? OTZ_BATCH_HOST_SNIFFED : 0u);
 	return OZG_OK;
 }
 
@@ -1185,7 +1243,7 @@ int ozg_decode_batch_device_ex(const void *d_src, uint64_t src_len, void *d_dst,
 		return OZG_E_ARG;
 	}
 	std::lock_guard<std::mutex> lk (g_mu);
-	return launch_decode (*C, d_src, src_len, d_dst, dst_len, d_entries, d_results, n, (hipStream_t)stream, batch_flags);
+	return launch_decode (*C, d_src, src_len, d_dst, dst_len, d_entries, d_results, n, (hipStream_t)stream, batch_flags & ~OTZ_BATCH_HOST_SNIFFED); // (nobody has looked at device-resident payloads)
 }
 
 int ozg_decode_batch_device(const void *d_src, uint64_t src_len, void *d_dst, uint64_t dst_len,

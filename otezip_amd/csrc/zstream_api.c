@@ -494,7 +494,11 @@ int deflateInit2(z_stream *strm, int level, int method, int windowBits, int memL
 	if (windowBits >= -15 && windowBits <= -8) {
 		wrap = OZS_WRAP_NONE;
 	} else if (windowBits >= 8 && windowBits <= 15) {
-		wrap = OZS_WRAP_ZLIB;
+		/* zlib's meaning (RFC 1950 framing, Adler-32 in strm->adler).  The reference writes raw DEFLATE here
+		 * too: a caller ported from it that frames the bytes itself (puts them into a ZIP entry, say) asks
+		 * for -15 -- or sets OTEZIP_DEFLATE_RAW_8_15=1, which restores the reference's reading of 8..15 */
+		const char *raw = getenv ("OTEZIP_DEFLATE_RAW_8_15");
+		wrap = raw && raw[0] && raw[0] != '0' ? OZS_WRAP_NONE : OZS_WRAP_ZLIB;
 	} else if (windowBits >= 24 && windowBits <= 31) {
 		wrap = OZS_WRAP_GZIP;
 	} else {

@@ -3,6 +3,8 @@ ozg_decode_batch_device), against the CPU oracle on the same seeded inputs, agai
 committed golden fixtures, and -- at BASELINE.json's full size -- through size-independent
 properties.  Bar: bit-exact output bytes, identical accept/reject (with the reference's F2
 false-reject repaired and flagged, SURVEY parity rule 2), identical CRC-32."""
+import os
+import sys
 import zlib
 
 import pytest
@@ -125,6 +127,65 @@ def test_device_resident_api(gpu_lib):
     for i, e in enumerate(ents):
         assert res[i, 0] == ST_OK and res[i, 2] == e["crc32"]
         assert zlib.crc32(host[et[i].dst_off:et[i].dst_off + e["uncomp_size"]].tobytes()) & 0xFFFFFFFF == e["crc32"]
+
+
+def test_device_resident_batch_of_every_method_is_sniffed_on_the_device(gpu_lib):
+    """Payloads that are only in HBM (ozg_decode_batch_device, no batch flags): the host cannot look at their first
+    bytes, so what the batch holds is counted on the device -- a real-format kernel none of whose streams is there
+    gets no launch and no scratch, the others scratch for what there is -- and the results are those of the staged
+    path.  The reference's framings under 93 / 100 / 97 / 14, DEFLATE, STORE, and (where the image has the
+    libraries) real Zstandard / Brotli / LZMA1 streams, interleaved."""
+    import lzma
+    import struct
+    import numpy as np
+    import torch
+    from otezip_amd import corpus, _native as N
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tools import brotlilib as B
+    from tools import zstdlib as Z
+    src, tab = bytearray(), []
+    datas = [corpus.gen_text(100 + i, 3000 + 977 * i) for i in range(24)]
+    for i, d in enumerate(datas):
+        kind = i % 8
+        if kind == 0:
+            m, comp = 8, corpus.raw_deflate(d)
+        elif kind == 1:
+            m, comp = 0, d
+        elif kind == 2:
+            m, comp = 93, corpus.frame_zstd_private(d)
+        elif kind == 3:
+            m, comp = 100, corpus.frame_lzfse_private(d)
+        elif kind == 4:
+            m, comp = 97, corpus.frame_brotli_private(d)
+        elif kind == 5 and B.available():
+            m, comp = 97, B.compress(d, quality=5)
+        elif kind == 6 and Z.available():
+            m, comp = 93, Z.compress(d, 3)
+        elif kind == 7:
+            f = [{"id": lzma.FILTER_LZMA1, "preset": 6, "lc": 3, "lp": 0, "pb": 2, "dict_size": 1 << 20}]
+            m, comp = 14, b"\x09\x14\x05\x00" + bytes([(2 * 5 + 0) * 9 + 3]) + struct.pack("<I", 1 << 20) + lzma.compress(d, format=lzma.FORMAT_RAW, filters=f)
+        else:
+            m, comp = 8, corpus.raw_deflate(d)
+        src += b"\x00" * (i % 5)
+        tab.append((m, len(src), len(comp), len(d), zlib.crc32(d) & 0xFFFFFFFF))
+        src += comp
+    for only_framings in (False, True):  # (second pass: no real stream at all -- none of the four kernels has work)
+        t = [x for k, x in enumerate(tab) if not (only_framings and k % 8 in (5, 6, 7))]
+        et, dst_len = gpu_lib.make_entries(t)
+        dev = torch.device("cuda", 0)
+        d_src = torch.frombuffer(bytearray(src), dtype=torch.uint8).to(dev)
+        d_dst = torch.zeros(dst_len, dtype=torch.uint8, device=dev)
+        d_ent = torch.frombuffer(bytearray(bytes(et)), dtype=torch.uint8).to(dev)
+        d_res = torch.zeros(len(t) * 16, dtype=torch.uint8, device=dev)
+        N.check(gpu_lib.lib().ozg_decode_batch_device(d_src.data_ptr(), d_src.numel(), d_dst.data_ptr(), d_dst.numel(),
+                                                      d_ent.data_ptr(), d_res.data_ptr(), len(t), torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        res = np.frombuffer(d_res.cpu().numpy().tobytes(), dtype=np.uint32).reshape(-1, 4)
+        host = d_dst.cpu().numpy()
+        staged = gpu_lib.decode_batch_host(bytes(src), t)
+        for i, (m, off, cs, us, crc) in enumerate(t):
+            assert res[i, 0] == ST_OK and res[i, 2] == crc, (i, m, int(res[i, 0]))
+            assert host[et[i].dst_off:et[i].dst_off + us].tobytes() == staged.data(i) and staged.ok(i), (i, m)
 
 
 def test_device_path_rejects_descriptors_outside_the_buffers(gpu_lib):

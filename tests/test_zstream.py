@@ -259,6 +259,24 @@ def test_deflate_frames_like_zlib_for_every_window_bits(gpu_lib):
     s, inb, out = _stream(b"x" * 100, 9)
     assert L.deflateInit2(C.byref(s), 6, 8, 31, 8, 0) == 0 and L.deflate(C.byref(s), Z_FINISH) == -5
     L.deflateEnd(C.byref(s))
+    # The one observable difference from the reference, pinned: windowBits 8..15 (what the deflateInit() macro
+    # passes) gives the RFC 1950 framing here and a raw stream there (ref deflate-enc.inc.c:207-215);
+    # OTEZIP_DEFLATE_RAW_8_15=1 restores the reference's reading for callers that frame the bytes themselves.
+    data = corpus.gen_text(7, 5000)
+    s, inb, out = _stream(data, len(data) + 300)
+    assert L.deflateInit2(C.byref(s), 6, 8, 15, 8, 0) == 0 and L.deflate(C.byref(s), Z_FINISH) == 1
+    framed = out.raw[:s.total_out]
+    L.deflateEnd(C.byref(s))
+    assert framed[0] & 0x0F == 8 and (framed[0] * 256 + framed[1]) % 31 == 0 and zlib.decompress(framed) == data
+    os.environ["OTEZIP_DEFLATE_RAW_8_15"] = "1"
+    try:
+        s, inb, out = _stream(data, len(data) + 300)
+        assert L.deflateInit2(C.byref(s), 6, 8, 15, 8, 0) == 0 and L.deflate(C.byref(s), Z_FINISH) == 1
+        raw = out.raw[:s.total_out]
+        L.deflateEnd(C.byref(s))
+    finally:
+        del os.environ["OTEZIP_DEFLATE_RAW_8_15"]
+    assert zlib.decompress(raw, -15) == data and len(raw) == len(framed) - 6
 
 
 @pytest.mark.gpu

@@ -12,6 +12,7 @@ for flags in "$@"; do
 	echo "==== variant $k: $flags"
 	touch otezip_amd/csrc/otz_kernels.hip
 	make -C otezip_amd/csrc EXTRA="$flags" 2>&1 | grep -E "error|VGPRs|Scratch" | head -2
+export OTEZIP_CORPUS_NO_FORK=1 # (from here on processes run under the profiler: a cache miss generates serially, it does not fork)
 	timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_$k -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_bench_$k.log 2>&1
 	find gpurun_out/prof_${tag}_$k -name "*kernel_stats.csv" | xargs cat | grep "otz_index" | cut -d, -f1-4
 done

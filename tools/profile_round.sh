@@ -12,6 +12,7 @@ echo "[profile] bench line"
 timeout -k 10 400 python3 bench.py --steps 20 --warmup 3 > $out/bench.json 2> $out/bench.err || tail -3 $out/bench.err
 cut -c1-300 $out/bench.json
 echo "[profile] kernel trace of bench.py"
+export OTEZIP_CORPUS_NO_FORK=1 # (from here on processes run under the profiler: a cache miss generates serially, it does not fork)
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_bench -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $out/trace_bench.log 2>&1
 find $out/trace_bench -name "*kernel_stats.csv" -exec cp {} $out/bench_kernel_stats.csv \;
 grep otz_ $out/bench_kernel_stats.csv | cut -d, -f1-4

@@ -10,6 +10,7 @@ prog=("$@")
 run() { # name counters...
 	local name=$1; shift
 	echo "[sq] pass ${name}: $@"
+export OTEZIP_CORPUS_NO_FORK=1 # (from here on processes run under the profiler: a cache miss generates serially, it does not fork)
 	timeout -k 10 150 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc_${tag}_${name} -- python3 "${prog[@]}" > gpurun_out/pmc_${tag}_${name}.log 2>&1 || { echo "[sq] pass ${name} failed"; tail -3 gpurun_out/pmc_${tag}_${name}.log; exit 1; }
 }
 # (at most four SQ counters per pass: a seven-counter pass hung on this pool)

@@ -19,7 +19,9 @@ def main():
     corpus.build_archive(min(n, 4000), 65536, methods=(8,))
     for k in (2000, 4000, 10000):
         corpus.build_archive(k, 65536)
-    corpus.text_buffers(10000, 65536, first=50000)
+    corpus.text_buffers(min(n, 10000), 65536, first=50000)  # (exactly what tools/bench_secondary.py asks for with this n)
+    if n != 10000:
+        corpus.text_buffers(10000, 65536, first=50000)
     try:
         zstd_corpus.build_zstd_real(max(n // 4, 100), 262144)
         zstd_corpus.build_zstd_real(n, 65536)
