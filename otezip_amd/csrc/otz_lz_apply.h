@@ -38,6 +38,9 @@
 #ifndef OTZ_A_RES_PRIO
 #define OTZ_A_RES_PRIO 1
 #endif
+#ifndef OTZ_A_RES_EAGER
+#define OTZ_A_RES_EAGER 0 // the resolution loop reads a step's source bytes together with their final bits
+#endif
 #ifndef OTZ_A_PLACE_V2
 #define OTZ_A_PLACE_V2 0 // the placement loop with one exit and the distance looked up for every lane (measured: no faster)
 #endif
@@ -370,9 +373,21 @@ OTZ_DEV void otz_resolve_list(otz_apply_lds &L, const otz_job &J, const u16 *lis
 		n = n < pdist ? n : pdist;
 		const u64 have = otz_ld64u (&L.fin[si >> 5]); // (n <= 16 bits: words si/32 and si/32 + 1 hold them)
 		otz_order_loads (); // "flag, then data": the source bytes are read after the bits that declare them final
+#if OTZ_A_RES_EAGER
+		// the source bytes are asked for together with the bits (dword-aligned reads: LDS reads past the bytes used
+		// land in the buffer's slack and are ignored): one LDS round trip per step, whether or not the step can go
+		const u32 *sp = reinterpret_cast<const u32 *> (&L.rbuf[si & ~3u]);
+		const u64 s01 = otz_ld64u (sp);
+		const u32 s2 = sp[2];
+		const u64 s34 = otz_ld64u (sp + 3);
+#endif
 		const u64 need = (((u64)1 << n) - 1u) << (si & 31u);
 		const bool go = pend != 0 && (have & need) == need;
 		if (go) {
+#if OTZ_A_RES_EAGER
+			const u32 s0 = (u32)s01, s1 = (u32) (s01 >> 32);
+			const u32 s3 = (u32)s34, s4 = (u32) (s34 >> 32);
+#else
 			// the source bytes: dword-aligned reads, then a byte funnel shift (LDS reads past the bytes
 			// used land in the buffer's slack and are ignored)
 			const u32 *sp = reinterpret_cast<const u32 *> (&L.rbuf[si & ~3u]);
@@ -384,6 +399,7 @@ OTZ_DEV void otz_resolve_list(otz_apply_lds &L, const otz_job &J, const u16 *lis
 				s3 = (u32)s34;
 				s4 = (u32) (s34 >> 32);
 			}
+#endif
 			const u32 q = si & 3u;
 			const u64 lo = otz_alignbyte (s1, s0, q) | ((u64)otz_alignbyte (s2, s1, q) << 32);
 			const u64 hi = otz_alignbyte (s3, s2, q) | ((u64)otz_alignbyte (s4, s3, q) << 32);
