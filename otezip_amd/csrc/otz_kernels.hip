@@ -48,12 +48,12 @@ static_assert (sizeof (otz_ix_head) == 32 && sizeof (otz_ix_block) == 32 && size
 #define OTZ_K1_WPE 5 // 7.6 KB of LDS admit 21 index wavefronts per CU: registers (<= 96) must not cut that to 16
 #endif
 #ifndef OTZ_K2_WGS
-#define OTZ_K2_WGS 4 // apply workgroups per CU
+#define OTZ_K2_WGS (OTZ_A_NT == 512u ? 4 : 8) // apply workgroups per CU
 #endif
 #ifndef OTZ_K2_WPE
-#define OTZ_K2_WPE (2 * OTZ_K2_WGS)
+#define OTZ_K2_WPE (OTZ_K2_WGS * (int)(OTZ_A_NT / 64u) / 4)
 #endif
-static_assert (sizeof (otz_apply_lds) <= 160 * 1024 / OTZ_K2_WGS, "apply workgroups per CU");
+static_assert ((sizeof (otz_apply_lds) + 1279u) / 1280u * OTZ_K2_WGS <= 128u, "apply workgroups per CU: LDS comes in 1280-byte granules, 128 of them");
 #define OTZ_BR_BIG_THREADS 512u // work-items of the Brotli kernel's second pass (832 KB of scratch each)
 #ifndef OTZ_ZS_WPE
 #define OTZ_ZS_WPE 4 // the Zstandard kernel's LDS (10.6 KB) admits 15 wavefronts per CU: registers must not halve that
@@ -140,10 +140,10 @@ otz_inflate_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result 
 	}
 }
 
-// OTZ_K2_WGS workgroups per CU (8 waves each, 2 per SIMD): pin the occupancy the LDS footprint
+// OTZ_K2_WGS workgroups per CU (OTZ_A_NT / 64 wavefronts each): pin the occupancy the LDS footprint
 // allows so a register-hungry change fails the resource check in tests/test_abi.py instead of
 // silently cutting the number of entries in flight.
-extern "C" __global__ void __launch_bounds__ (OTZ_NT) __attribute__ ((amdgpu_waves_per_eu (OTZ_K2_WPE, OTZ_K2_WPE)))
+extern "C" __global__ void __launch_bounds__ (OTZ_A_NT) __attribute__ ((amdgpu_waves_per_eu (OTZ_K2_WPE, 8)))
 otz_apply_kernel(const u8 *src, u8 *dst, const ozg_entry *entries, ozg_result *results, u32 first, u32 n, u64 src_len, u64 dst_len, ozg_limits lim,
 	const u8 *arena, const otz_region *regions, const otz_ix_head *heads, u64 *prof, u64 *end_bits) {
 	extern __shared__ __attribute__ ((aligned (16))) u8 otz_smem[];
@@ -861,7 +861,7 @@ int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, 
 				ws.busy = true;
 				return OZG_OK;
 			}
-			hipLaunchKernelGGL (otz_apply_kernel, dim3 (n), dim3 (OTZ_NT), sizeof (otz_apply_lds), s, (const u8 *)d_src, (u8 *)d_dst,
+			hipLaunchKernelGGL (otz_apply_kernel, dim3 (n), dim3 (OTZ_A_NT), sizeof (otz_apply_lds), s, (const u8 *)d_src, (u8 *)d_dst,
 				d_entries, d_results, 0u, n, (u64)src_len, (u64)dst_len, g_limits, (const u8 *)ws.arena, ws.regions, ws.heads, g_prof, d_end_bits);
 			OZG_HIP (hipGetLastError ());
 			hipLaunchKernelGGL (otz_out_crc_kernel, dim3 (n), dim3 (256), sizeof (otz_copy_lds), s, (const u8 *)d_dst, d_entries, d_results, 0u, n);
@@ -881,7 +881,7 @@ int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, 
 				hipLaunchKernelGGL (otz_index_kernel, dim3 (e1 - e0), dim3 (64), sizeof (otz_k1_lds), cs, (const u8 *)d_src, (u8 *)d_dst, d_entries, e0, n,
 					(u64)src_len, (u64)dst_len, g_limits, ws.arena, ws.regions, ws.heads, ws.ovf, g_prof);
 				OZG_HIP (hipGetLastError ());
-				hipLaunchKernelGGL (otz_apply_kernel, dim3 (e1 - e0), dim3 (OTZ_NT), sizeof (otz_apply_lds), cs, (const u8 *)d_src, (u8 *)d_dst,
+				hipLaunchKernelGGL (otz_apply_kernel, dim3 (e1 - e0), dim3 (OTZ_A_NT), sizeof (otz_apply_lds), cs, (const u8 *)d_src, (u8 *)d_dst,
 					d_entries, d_results, e0, n, (u64)src_len, (u64)dst_len, g_limits, (const u8 *)ws.arena, ws.regions, ws.heads, g_prof, d_end_bits);
 				OZG_HIP (hipGetLastError ());
 				hipLaunchKernelGGL (otz_out_crc_kernel, dim3 (e1 - e0), dim3 (256), sizeof (otz_copy_lds), cs, (const u8 *)d_dst, d_entries, d_results, e0, n);

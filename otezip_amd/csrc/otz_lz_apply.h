@@ -1,9 +1,9 @@
-// otz_lz_apply.h -- second half of the DEFLATE decode: one 512-lane workgroup turns the
-// index of otz_index.h into the entry's bytes.  (ref: the output side of inflate(),
+// otz_lz_apply.h -- second half of the DEFLATE decode: one workgroup of OTZ_A_NT work-items (256: four
+// wavefronts, eight such workgroups per CU) turns the index of otz_index.h into the entry's bytes.  (ref: the output side of inflate(),
 // src/lib/deflate-dec.inc.c:693-812 -- literal store, do_copy_from_window :521-545.)
 //
 // Per Huffman block: rebuild the decode tables from the stored code lengths (all lanes),
-// then take the block's items 512 at a time (fewer when their output would not fit one
+// then take the block's items OTZ_A_NT at a time (fewer when their output would not fit one
 // round, or their bits the stage buffer): lane j decodes item j -- at most OTZ_IX_G tokens
 // between two known token boundaries, at a known output position.  Literals go to their
 // final bytes of the round buffer in LDS, matches are parked at their destination and
@@ -21,20 +21,36 @@
 #include "otz_inflate.h"
 #include "otz_index.h"
 
+#ifndef OTZ_A_NT
+#define OTZ_A_NT 256u     // work-items of the apply kernel's workgroup: 256 or 512
+#endif
+// The sizes below put the workgroup's LDS at 16 allocation granules of 1280 bytes, so that eight workgroups share
+// a CU (32 wavefronts: every SIMD full at <= 64 registers).  Measured, ms per step of the benchmark on one box:
+// 512 work-items x 4 workgroups (4 KiB window, 16 KiB rounds) 2.51-2.53; 256 x 7 (2 KiB window, 8 KiB rounds)
+// 2.40-2.43; 256 x 8 with the sizes below 2.395, with 128 resolving work-items 2.34.
 #ifndef OTZ_A_RMAX
-#define OTZ_A_RMAX 16384u // output bytes per round
+#define OTZ_A_RMAX (OTZ_A_NT * 28u) // output bytes per round, at most (OTZ_A_NT items of <= OTZ_IX_G tokens come to about NT * 29 bytes of text)
 #endif
 #ifndef OTZ_A_WIN
-#define OTZ_A_WIN 4096u   // bytes before the round kept in LDS (a multiple of 16)
+#define OTZ_A_WIN (OTZ_A_NT * 4u) // bytes before the round kept in LDS (a multiple of 16)
 #endif
+#ifndef OTZ_A_STAGE_PER
+#define OTZ_A_STAGE_PER 16u
+#endif
+#define OTZ_A_STAGE_BYTES (OTZ_A_NT * OTZ_A_STAGE_PER) // the round's compressed bytes (16 bits a token on average; more: a shorter round), then its match lists
+#define OTZ_A_STAGE_WORDS (OTZ_A_STAGE_BYTES / 4u)
+static_assert (OTZ_A_NT == 512u || OTZ_A_NT == 256u, "eight or four wavefronts");
 // The resolution loop is a chain of dependent iterations (as many as the round's longest chain of matches copying
 // from matches: 5-25), so what counts is how long ONE iteration takes, and that is set by how many wavefronts of
 // the CU are in it: half of the workgroup's wavefronts resolve, at raised priority, the others wait at the barrier
 // and leave their issue slots to the bulk phases of the other workgroups.  Measured (ms per step of the
-// benchmark): 512 work-items 2.68, with priority 2.68; 256 with priority 2.57; 128 2.61; 192 / 320 2.59.
+// benchmark), 512-lane workgroups: all 512 resolving 2.68, with priority 2.68; 256 with priority 2.57; 128 2.61;
+// 192 / 320 2.59.  256-lane workgroups, 7 per CU: 256 resolving 2.43, 192 2.42, 128 2.38-2.41, 64 2.43; without
+// the raised priority 2.43.
 #ifndef OTZ_A_RES_LANES
-#define OTZ_A_RES_LANES 256u // work-items that resolve the round's matches (whole wavefronts; the others wait at the barrier)
+#define OTZ_A_RES_LANES (OTZ_A_NT / 2u) // work-items that resolve the round's matches (whole wavefronts; the others wait at the barrier)
 #endif
+static_assert (OTZ_A_RES_LANES <= OTZ_A_NT && OTZ_A_RES_LANES % 64u == 0, "whole wavefronts of the workgroup");
 #ifndef OTZ_A_RES_PRIO
 #define OTZ_A_RES_PRIO 1
 #endif
@@ -54,8 +70,8 @@ struct otz_apply_lds {
 	u32 lit_lut[OTZ_LIT_LUT];
 	u32 dist_lut[OTZ_DIST_LUT];
 	union {
-		u32 stage_w[OTZ_STAGE_WORDS];
-		u8 stage[OTZ_STAGE_BYTES];
+		u32 stage_w[OTZ_A_STAGE_WORDS];
+		u8 stage[OTZ_A_STAGE_BYTES];
 	};
 	union {
 		u32 fin[OTZ_A_FIN_WORDS];
@@ -81,6 +97,208 @@ struct otz_a_pos {
 	u32 opos, flushed, p0;
 };
 
+// ---------------------------------------------------------------- workgroup helpers
+//
+// Inclusive prefix sum over the workgroup's OTZ_A_NT work-items; *total gets the sum.  Uniform control flow.
+OTZ_DEV u32 otz_a_block_scan_incl(u32 v, u32 *scratch, u32 *total) {
+	const u32 lane = otz_lane ();
+	v = otz_wave_scan_incl (v);
+	otz_sync ();
+	if (lane == 63u) {
+		scratch[otz_wave ()] = v;
+	}
+	otz_sync ();
+	u32 add = 0, tot = 0;
+	for (u32 w = 0; w < OTZ_A_NT / 64u; w++) {
+		const u32 x = scratch[w];
+		if (w < otz_wave ()) {
+			add += x;
+		}
+		tot += x;
+	}
+	*total = tot;
+	return v + add;
+}
+
+// Both two-level decode tables from L.ll[0..hlit+hdist): the construction of otz_build_tables (otz_inflate.h: a
+// symbol's canonical code is first[len] + its rank among the symbols of the same length, ranks from wavefront
+// ballots, the symbol writes its own root slots or claims a sub-table under its root slot) for a workgroup of
+// OTZ_A_NT work-items: the symbols are taken in chunks of 64 -- chunks 0..4 the 288 literal/length symbols
+// (320 slots), chunk 5 the 32 distance symbols -- wavefront w takes chunks w, w + OTZ_A_NT / 64, ...; the root
+// slots OTZ_A_NT at a time.  Returns false (uniformly) on an over-subscribed set, or if the sub-tables do not fit.
+OTZ_DEV bool otz_a_build_tables(otz_apply_lds &L, u32 hlit, u32 hdist) {
+	constexpr u32 LRSZ = 1u << OTZ_LIT_ROOT, DRSZ = 1u << OTZ_DIST_ROOT;
+	constexpr u32 NW = OTZ_A_NT / 64u, PASSES = (6u + NW - 1u) / NW;
+	static_assert (OTZ_A_NT >= 128u, "wavefronts 0 and 1 do the canonical bookkeeping");
+	// (opaque: nothing derived from them is computed once before the caller's block loop and kept -- spilled -- across it)
+	const u32 tid = otz_opaque (otz_tid ()), lane = otz_opaque (otz_lane ()), wave = otz_opaque (otz_wave ());
+	const u64 below = ((u64)1 << lane) - 1u;
+	for (u32 i = tid; i < OTZ_LIT_LUT; i += OTZ_A_NT) {
+		L.lit_lut[i] = OTZ_LUT_NONE;
+	}
+	for (u32 i = tid; i < OTZ_DIST_LUT; i += OTZ_A_NT) {
+		L.dist_lut[i] = OTZ_LUT_NONE;
+	}
+	// this work-item's symbols: one per pass
+	u32 ls[PASSES], ranks[PASSES];
+#pragma unroll
+	for (u32 p = 0; p < PASSES; p++) {
+		const u32 chunk = wave + p * NW;
+		const u32 slot = 64u * chunk + lane; // 0..287: literal/length symbols, 320..351: distance symbols
+		u32 l = 0;
+		if (chunk < 5u && slot < hlit) {
+			l = L.ll[slot];
+		} else if (chunk == 5u && slot - 320u < hdist) {
+			l = L.ll[hlit + slot - 320u];
+		}
+		u32 rank = 0; // symbols of the same length before this one in its chunk
+		if (chunk < 6u) {
+			if (lane < 16u) {
+				L.wcnt[chunk][lane] = 0; // (the counts below come from the same wavefront: LDS keeps its order)
+			}
+			u64 rem = otz_ballot (l != 0); // one ballot per code length that occurs in this chunk
+			while (rem != 0) {
+				const u32 k = otz_readlane (l, otz_ctz64 (rem));
+				const u64 m = otz_ballot (l == k);
+				if (l == k) {
+					rank = otz_popc64 (m & below);
+				}
+				if (lane == 0) {
+					L.wcnt[chunk][k] = otz_popc64 (m);
+				}
+				rem &= ~m;
+			}
+		}
+		ls[p] = l;
+		ranks[p] = rank;
+	}
+	otz_sync ();
+	// Canonical bookkeeping, one lane per code length (wavefront 0: literal/length code, wavefront 1: distance
+	// code): first[l] = sum over j < l of count[j] << (l - j), off[l] = sum over j < l of count[j].  A set is
+	// over-subscribed (ref: "left < 0") exactly when first[15] + count[15] exceeds 2^15.
+	if (wave < 2u) {
+		u32 cnt = 0;
+		if (lane >= 1u && lane < 16u) {
+			const u32 *wc = &L.wcnt[0][0] + lane; // one address, constant offsets
+			cnt = wave == 1u ? wc[80] : wc[0] + wc[16] + wc[32] + wc[48] + wc[64];
+		}
+		u32 code = 0, off = 0;
+		for (u32 j = 1; j < 15u; j++) {
+			const u32 cj = otz_shfl (cnt, j);
+			if (lane > j && lane < 16u) {
+				code += cj << (lane - j);
+				off += cj;
+			}
+		}
+		if (lane < 16u) {
+			otz_canon &c = wave == 1u ? L.dist_c : L.lit_c;
+			c.first[lane] = (u16)code;
+			c.count[lane] = (u16)cnt;
+			c.off[lane] = (u16)off;
+		}
+		if (lane == 15u) {
+			const u32 ok = code + cnt <= (1u << 15) ? 1u : 0u;
+			if (wave == 0) {
+				L.flag = ok;
+			} else {
+				L.first_rej = ok;
+			}
+		}
+	}
+	otz_sync ();
+	if (L.flag == 0u || L.first_rej == 0u) {
+		return false;
+	}
+	// the symbols' codes, bit-reversed (DEFLATE sends codes most significant bit first)
+	u32 rrs[PASSES], es[PASSES];
+#pragma unroll
+	for (u32 p = 0; p < PASSES; p++) {
+		const u32 chunk = wave + p * NW;
+		const bool is_dist = chunk == 5u;
+		const u32 sym = is_dist ? lane : 64u * chunk + lane;
+		const u32 root = is_dist ? OTZ_DIST_ROOT : OTZ_LIT_ROOT, rsz = is_dist ? DRSZ : LRSZ;
+		u32 *const lut = is_dist ? L.dist_lut : L.lit_lut;
+		const u32 l = ls[p];
+		u32 rr = 0, e = 0;
+		if (l) {
+			const otz_canon &c = is_dist ? L.dist_c : L.lit_c;
+			u32 before = ranks[p];
+			for (u32 w = 0; w < chunk && !is_dist; w++) {
+				before += L.wcnt[w][l];
+			}
+			rr = otz_brev ((u32)c.first[l] + before) >> (32u - l);
+			e = is_dist ? otz_mk_dist_entry (sym, l) : otz_mk_lit_entry (sym, l);
+			if (l > root) {
+				otz_lds_max (&lut[rr & (rsz - 1u)], (l - root) << 8); // widest code under this root slot
+			} else if (l + 5u > root) {
+				for (u32 idx = rr; idx < rsz; idx += 1u << l) { // at most sixteen root slots
+					lut[idx] = e;
+				}
+			}
+		}
+		if (chunk < 6u) {
+			// A very short code owns many root slots (a 4-bit literal code 32 of the 512): the wavefront fills those
+			// together, a symbol at a time, instead of waiting for the lane that owns the most.
+			u64 heavy = otz_ballot (l != 0 && l + 5u <= root);
+			while (heavy != 0) {
+				const u32 hs = otz_ctz64 (heavy);
+				heavy &= heavy - 1u;
+				const u32 lh = otz_readlane (l, hs), rh = otz_readlane (rr, hs), eh = otz_readlane (e, hs);
+				for (u32 idx = rh + (lane << lh); idx < rsz; idx += 64u << lh) {
+					lut[idx] = eh;
+				}
+			}
+		}
+		rrs[p] = rr;
+		es[p] = e;
+	}
+	otz_sync ();
+	// sub-table placement: one prefix sum over the root slots of both tables (literal sizes in the low half of the
+	// scanned word, distance sizes in the high half), OTZ_A_NT root slots at a time
+	u32 carry = 0;
+	bool fits = true;
+	for (u32 base = 0; base < LRSZ; base += OTZ_A_NT) {
+		const u32 slot = base + tid;
+		const u32 el = L.lit_lut[slot < LRSZ ? slot : 0u], ed = L.dist_lut[slot < DRSZ ? slot : 0u];
+		// a root slot claimed by longer codes holds (widest code - root) << 8 at this point
+		const u32 ml = slot < LRSZ && el && (el & 0xFFu) == 0 ? 1u << (el >> 8) : 0u;
+		const u32 md = slot < DRSZ && ed && (ed & 0xFFu) == 0 ? 1u << (ed >> 8) : 0u;
+		u32 total;
+		const u32 incl = carry + otz_a_block_scan_incl (ml | (md << 16), L.scan, &total);
+		carry += total;
+		fits = fits && (carry & 0xFFFFu) <= OTZ_LIT_LUT - LRSZ && (carry >> 16) <= OTZ_DIST_LUT - DRSZ;
+		if (fits) {
+			if (ml) {
+				L.lit_lut[slot] = OTZ_LUT_LINK | ((LRSZ + (incl & 0xFFFFu) - ml) << 16) | ((el >> 8) << 8) | OTZ_LUT_NONE;
+			}
+			if (md) {
+				L.dist_lut[slot] = OTZ_LUT_LINK | ((DRSZ + (incl >> 16) - md) << 16) | ((ed >> 8) << 8) | OTZ_LUT_NONE;
+			}
+		}
+		otz_sync ();
+	}
+	if (!fits) {
+		return false;
+	}
+#pragma unroll
+	for (u32 p = 0; p < PASSES; p++) {
+		const u32 chunk = wave + p * NW;
+		const bool is_dist = chunk == 5u;
+		const u32 root = is_dist ? OTZ_DIST_ROOT : OTZ_LIT_ROOT, rsz = is_dist ? DRSZ : LRSZ;
+		u32 *const lut = is_dist ? L.dist_lut : L.lit_lut;
+		const u32 l = ls[p];
+		if (l > root) {
+			const u32 link = lut[rrs[p] & (rsz - 1u)];
+			const u32 sb = (link >> 8) & 15u, sbase = (link >> 16) & 0x7FFFu;
+			for (u32 idx = rrs[p] >> root; idx < (1u << sb); idx += 1u << (l - root)) {
+				lut[sbase + idx] = es[p];
+			}
+		}
+	}
+	otz_sync ();
+	return true;
+}
+
 // ---------------------------------------------------------------- placement
 //
 // Lane j decodes item j: at most OTZ_IX_G tokens from stage bit s_bit up to e_bit, first
@@ -92,10 +310,10 @@ struct otz_a_pos {
 // away -- and a step reloads its three stage words instead of sliding a window.
 // Afterwards the destinations of all matches of the round are written, in stream order, to
 // `list` (buffer positions, u16): a prefix sum over the lanes' match counts gives every lane
-// its slice.  Returns the number of matches of the round.  All OTZ_NT work-items.
+// its slice.  Returns the number of matches of the round.  All OTZ_A_NT work-items.
 static_assert (OTZ_IX_G == 8u, "eight 16-bit destinations are packed into four 32-bit registers");
-#define OTZ_A_LIST_CAP (OTZ_NT * OTZ_IX_G) // matches of a round, at most
-static_assert (OTZ_A_LIST_CAP * 2u <= OTZ_STAGE_BYTES, "the match lists of a round fit the stage buffer");
+#define OTZ_A_LIST_CAP (OTZ_A_NT * OTZ_IX_G) // matches of a round, at most
+static_assert (OTZ_A_LIST_CAP * 2u <= OTZ_A_STAGE_BYTES, "the match lists of a round fit the stage buffer");
 OTZ_DEV u32 otz_place_items(otz_apply_lds &L, bool active, u32 s_bit, u32 e_bit, u32 ri, u32 p0, u16 *list, u32 *n_far) {
 	u32 nm = 0;
 	u32 k0 = 0, k1 = 0, k2 = 0, k3 = 0; // the matches' destinations, newest in the low half of k0
@@ -220,7 +438,7 @@ OTZ_DEV u32 otz_place_items(otz_apply_lds &L, bool active, u32 s_bit, u32 e_bit,
 	// starts in the entry's output in global memory from the end of the list's room downwards (in any order)
 	const u32 nf = otz_popc (farm), nn = nm - nf;
 	u32 total;
-	const u32 incl = otz_block_scan_incl (nn | (nf << 16), L.scan, &total); // (two barriers: every stage read is done)
+	const u32 incl = otz_a_block_scan_incl (nn | (nf << 16), L.scan, &total); // (two barriers: every stage read is done)
 	const u32 at_n = (incl & 0xFFFFu) - nn, at_f = (incl >> 16) - nf;
 	// match number q (in stream order) is the (nm - 1 - q)-th newest
 #pragma unroll
@@ -280,7 +498,7 @@ OTZ_DEV void otz_a_put(otz_apply_lds &L, u32 o, u64 lo, u64 hi, u32 n) {
 // made first, all of a lane's loads in flight together -- one trip to the L2 per round instead of one inside
 // every iteration of the resolution loop below.  (The part of a source that lies in the buffer is read there.)
 OTZ_DEV void otz_far_copies(otz_apply_lds &L, const otz_job &J, u32 p0, const u16 *list, u32 n_far) {
-	for (u32 m = otz_tid (); m < n_far; m += OTZ_NT) {
+	for (u32 m = otz_tid (); m < n_far; m += OTZ_A_NT) {
 		u32 o = list[OTZ_A_LIST_CAP - 1u - m];
 		const u64 dw = otz_ld64u (&L.rbuf[o & ~3u]);
 		const u32 cd = otz_alignbyte ((u32) (dw >> 32), (u32)dw, o) & 0xFFFFFFu;
@@ -454,8 +672,8 @@ OTZ_DEV void otz_a_stage(otz_apply_lds &L, const otz_job &J, u32 byte0, u32 n_by
 	const u8 *ga = p - skew;
 	const u8 *lo = J.in, *hi = J.in + J.n_in;
 	u32 chunks = (skew + n_bytes + 15u) >> 4;
-	chunks = chunks < OTZ_STAGE_BYTES / 16u ? chunks : OTZ_STAGE_BYTES / 16u;
-	for (u32 c = otz_opaque (otz_tid ()); c < chunks; c += OTZ_NT) { // (opaque: no per-lane address kept across the rounds)
+	chunks = chunks < OTZ_A_STAGE_BYTES / 16u ? chunks : OTZ_A_STAGE_BYTES / 16u;
+	for (u32 c = otz_opaque (otz_tid ()); c < chunks; c += OTZ_A_NT) { // (opaque: no per-lane address kept across the rounds)
 		const u8 *a = ga + 16u * c;
 		otz_u4 v;
 		if (a >= lo && a + 16 <= hi) {
@@ -487,7 +705,7 @@ OTZ_DEV void otz_a_stage(otz_apply_lds &L, const otz_job &J, u32 byte0, u32 n_by
 // Start of a round: nothing after the decoded bytes is final.  (ll shares the bitmap's storage.)
 OTZ_DEV void otz_a_begin(otz_apply_lds &L, const otz_a_pos &P) {
 	const u32 h = P.opos - P.p0;
-	for (u32 i = otz_tid (); i < OTZ_A_FIN_WORDS; i += OTZ_NT) {
+	for (u32 i = otz_tid (); i < OTZ_A_FIN_WORDS; i += OTZ_A_NT) {
 		L.fin[i] = i < h >> 5 ? 0xFFFFFFFFu : i == h >> 5 ? (1u << (h & 31u)) - 1u : 0u;
 	}
 }
@@ -499,19 +717,19 @@ OTZ_DEV void otz_a_advance(otz_apply_lds &L, const otz_job &J, otz_a_pos &P, u32
 	const u32 tid = otz_tid ();
 	const u32 end = P.opos + produced;
 	const u32 up = end & ~15u;
-	for (u32 c = tid; c < (up - P.flushed) >> 4; c += OTZ_NT) {
+	for (u32 c = tid; c < (up - P.flushed) >> 4; c += OTZ_A_NT) {
 		otz_st16_aligned (J.out + P.flushed + 16u * c, otz_ld16_aligned (&L.rbuf[P.flushed - P.p0 + 16u * c]));
 	}
 	P.flushed = up;
 	P.opos = end;
 	const u32 keep = up > OTZ_A_WIN ? up - OTZ_A_WIN : 0u;
 	if (keep > P.p0) {
-		constexpr u32 CH = (OTZ_A_WIN / 16u + 1u + OTZ_NT - 1u) / OTZ_NT;
+		constexpr u32 CH = (OTZ_A_WIN / 16u + 1u + OTZ_A_NT - 1u) / OTZ_A_NT;
 		const u32 d = keep - P.p0, chunks = (end - keep + 15u) >> 4;
 		otz_u4 t[CH];
 #pragma unroll
 		for (u32 k = 0; k < CH; k++) {
-			const u32 c = tid + k * OTZ_NT;
+			const u32 c = tid + k * OTZ_A_NT;
 			if (c < chunks) {
 				t[k] = otz_ld16_aligned (&L.rbuf[d + 16u * c]);
 			}
@@ -519,7 +737,7 @@ OTZ_DEV void otz_a_advance(otz_apply_lds &L, const otz_job &J, otz_a_pos &P, u32
 		otz_sync ();
 #pragma unroll
 		for (u32 k = 0; k < CH; k++) {
-			const u32 c = tid + k * OTZ_NT;
+			const u32 c = tid + k * OTZ_A_NT;
 			if (c < chunks) {
 				otz_st16_aligned (&L.rbuf[16u * c], t[k]);
 			}
@@ -543,7 +761,7 @@ OTZ_DEV u8 otz_a_byte(const otz_apply_lds &L, const otz_job &J, const otz_a_pos 
 	return p < P.p0 ? J.out[p] : L.rbuf[p - P.p0];
 }
 
-// All OTZ_NT work-items.  Work-item 0 writes *res (crc32 and the CRC flag are left to the CRC pass).
+// All OTZ_A_NT work-items.  Work-item 0 writes *res (crc32 and the CRC flag are left to the CRC pass).
 // end_bit (optional): where the stream ended, for the z_stream seam's total_in.
 OTZ_DEV void otz_apply_entry(otz_apply_lds &L, const otz_job &J, const otz_ix_head *head, const u8 *region, ozg_result *res, u64 *end_bit) {
 	const u32 tid = otz_tid ();
@@ -596,7 +814,7 @@ OTZ_DEV void otz_apply_entry(otz_apply_lds &L, const otz_job &J, const otz_ix_he
 			while (done < out_len) {
 				const u32 n = out_len - done < OTZ_A_RMAX ? out_len - done : OTZ_A_RMAX;
 				const u32 h = P.opos - P.p0;
-				for (u32 i = tid; i < n; i += OTZ_NT) {
+				for (u32 i = tid; i < n; i += OTZ_A_NT) {
 					L.rbuf[h + i] = J.in[src_byte + done + i];
 				}
 				otz_sync ();
@@ -608,11 +826,11 @@ OTZ_DEV void otz_apply_entry(otz_apply_lds &L, const otz_job &J, const otz_ix_he
 			continue;
 		}
 		// ---- Huffman block: tables from the stored code lengths
-		if (tid < OTZ_IX_LENS) {
-			L.ll[tid] = region[boff + 32u + tid];
+		for (u32 i = tid; i < OTZ_IX_LENS; i += OTZ_A_NT) {
+			L.ll[i] = region[boff + 32u + i];
 		}
 		otz_sync ();
-		if (!otz_build_tables (L, hlit, hdist)) {
+		if (!otz_a_build_tables (L, hlit, hdist)) {
 			otz_fail_all (L, OZG_ST_INTERNAL);
 			break;
 		}
@@ -630,10 +848,10 @@ OTZ_DEV void otz_apply_entry(otz_apply_lds &L, const otz_job &J, const otz_ix_he
 			const u32 skew = (u32) ((uintptr_t) (J.in + byte0) & 15u);
 			const u32 p0 = skew * 8u + (u32) (abs0 & 7u);
 			// a walk reads up to five words past the one holding its position
-			const u32 bit_room = 8u * OTZ_STAGE_BYTES - 192u - p0;
+			const u32 bit_room = 8u * OTZ_A_STAGE_BYTES - 192u - p0;
 			const bool fits = base + tid < n_items && z.out - first.out <= OTZ_A_RMAX && z.bit - first.bit <= bit_room && z.out >= a.out && z.bit >= a.bit;
 			if (tid == 0) {
-				L.first_rej = OTZ_NT;
+				L.first_rej = OTZ_A_NT;
 				L.flag = 0;
 			}
 			otz_sync ();
@@ -679,7 +897,7 @@ OTZ_DEV void otz_apply_entry(otz_apply_lds &L, const otz_job &J, const otz_ix_he
 #if OTZ_A_RES_PRIO
 			otz_set_priority_high (); // (the resolution loop goes first, the bulk phases of the other workgroups fill the gaps)
 #endif
-			if (OTZ_A_RES_LANES == OTZ_NT || tid < OTZ_A_RES_LANES) {
+			if (OTZ_A_RES_LANES == OTZ_A_NT || tid < OTZ_A_RES_LANES) {
 				otz_resolve_list (L, J, list, n_matches);
 			}
 #if OTZ_A_RES_PRIO
@@ -710,7 +928,8 @@ OTZ_DEV void otz_apply_entry(otz_apply_lds &L, const otz_job &J, const otz_ix_he
 		// written, the entry reports OZG_ST_NEED_OUT.  (The tables of the last block are still up.)
 		const u64 clip = ((u64)head->clip_hi << 32) | head->clip_lo;
 		const u32 byte0 = (u32) (clip >> 3);
-		const u32 skew = otz_stage_load (L, J, byte0);
+		const u32 skew = (u32) ((uintptr_t) (J.in + byte0) & 15u);
+		otz_a_stage (L, J, byte0, 32u);
 		otz_sync ();
 		const u32 p = skew * 8u + (u32) (clip & 7u);
 		const u32 w = p >> 5;
@@ -755,7 +974,7 @@ OTZ_DEV void otz_apply_entry(otz_apply_lds &L, const otz_job &J, const otz_ix_he
 			}
 			const otz_u4 zero = { 0, 0, 0, 0 };
 			u32 c = a16 + 16u * tid;
-			for (; c + 16u <= J.out_cap; c += 16u * OTZ_NT) {
+			for (; c + 16u <= J.out_cap; c += 16u * OTZ_A_NT) {
 				otz_st16_aligned (J.out + c, zero);
 			}
 			if (c < J.out_cap) { // (one work-item: the partial chunk at the very end)

@@ -366,7 +366,7 @@ extern "C" int emu_decode_batch_mode(const void *src, uint64_t src_len, void *ds
 			fprintf (stderr, "[emu] entry %u: index status %d, %u blocks, %u bytes\n", i, head.status, head.n_blocks, head.total_out);
 		}
 		a.phase = 2;
-		run_block (OTZ_NT, a, sizeof (otz_apply_lds));
+		run_block (OTZ_A_NT, a, sizeof (otz_apply_lds));
 		if (results[i].status == OZG_ST_OK) {
 			a.phase = 7;
 			run_block (OTZ_CNT, a, lds_bytes);
