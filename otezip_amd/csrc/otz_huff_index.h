@@ -88,8 +88,6 @@ static_assert ((OTZ_IX_G & (OTZ_IX_G - 1u)) == 0, "power of two");
 #endif
 
 struct otz_k1_lds {
-	u16 lit[OTZ_K1_LLUT];
-	u16 dist[OTZ_K1_DLUT];
 	union {
 		u32 win[OTZ_K1_WROWS * 64u]; // [row][lane]: the piece every lane has staged
 		struct { // block prologue only
@@ -100,7 +98,11 @@ struct otz_k1_lds {
 			u8 subw[1u << OTZ_K1_LROOT]; // per root slot: index width of its sub-table (0: none)
 		} h;
 	};
+	// (behind the window: the walk's look-ahead reads two rows past it and ignores what it gets)
+	u16 lit[OTZ_K1_LLUT];
+	u16 dist[OTZ_K1_DLUT];
 };
+static_assert (OTZ_K1_LLUT * 2u >= 2u * 256u, "two window rows of look-ahead stay inside the LDS block");
 static_assert (OTZ_K1_P != 512u || sizeof (otz_k1_lds) <= 6u * 1280u, "twenty wavefronts per CU: six 1280-byte granules of LDS each");
 
 // ------------------------------------------------------------------ wave helpers
@@ -517,9 +519,7 @@ struct otz_k1_step {
 	u32 ob;   // bytes it yields
 	bool stop;
 };
-OTZ_DEV otz_k1_step otz_k1_hot(const otz_k1_lds &L, u32 lb, u32 u) {
-	u32 w0, w1, w2;
-	otz_k1_words (L, lb, u, w0, w1, w2);
+OTZ_DEV otz_k1_step otz_k1_hot_w(const otz_k1_lds &L, u32 w0, u32 w1, u32 w2, u32 u) {
 	const u32 lo = otz_alignbit (w1, w0, u), hi = otz_alignbit (w2, w1, u);
 	u32 e = L.lit[lo & ((1u << OTZ_K1_LROOT) - 1u)];
 	u32 xb = otz_bfe (e, 4, 3);
@@ -541,6 +541,11 @@ OTZ_DEV otz_k1_step otz_k1_hot(const otz_k1_lds &L, u32 lb, u32 u) {
 	r.nb = used + (is_len ? d : 0u);
 	r.ob = B + otz_bfe (lo, len, xb);
 	return r;
+}
+OTZ_DEV otz_k1_step otz_k1_hot(const otz_k1_lds &L, u32 lb, u32 u) {
+	u32 w0, w1, w2;
+	otz_k1_words (L, lb, u, w0, w1, w2);
+	return otz_k1_hot_w (L, w0, w1, w2, u);
 }
 
 // How a walk that stopped at slot-relative bit u (in front of e, inside the staged piece) ends: the exit word.
@@ -589,6 +594,9 @@ struct otz_k1_ws {
 // raising a bit above every position in its own u (a break out of the middle of the body costs a dozen scalar
 // instructions of execution-mask bookkeeping per way out, every iteration), and a step that must not count is
 // computed and then not added.
+#ifndef OTZ_K1_SLIDE
+#define OTZ_K1_SLIDE 0 // 1: the walk loop carries its window words from step to step (measured: no faster)
+#endif
 #define OTZ_K1_HALT 0x80000000u
 #define OTZ_K1_MERGE 0x40000000u
 #define OTZ_K1_YOUNG 768u // bits: a guessed chain that stops in the first so many bits of its segment starts over
@@ -607,6 +615,13 @@ OTZ_DEV void otz_k1_walk_loop(const otz_k1_lds &L, u32 lb, otz_k1_ws &W, u32 pen
 	// bookkeeping): a chain that has come that far has met the real one, and what stops it then stops the block.
 	// (Whatever walk A does is a hint: the true path is walk B's, up to where it lands on walk A's chain.)
 	const bool may_restart = SPEC && YOUNG && otz_lane () != 0;
+#if OTZ_K1_SLIDE
+	// The three window words of the token at u are carried from step to step: a token is at most 48 bits, so the
+	// next one starts in the same word or one of the next two, and the two words that may slide in are asked for
+	// BEFORE this step's lookups -- the step waits for its table entries, not for the window and then the entries.
+	u32 w0, w1, w2;
+	otz_k1_words (L, lb, u < pend ? u : pend - 1u, w0, w1, w2); // (a lane that stays out of the loop: any word of the piece)
+#endif
 	while (u < pend && cnt < ncap) {
 		bool hit = false;
 		if (!SPEC) {
@@ -631,7 +646,14 @@ OTZ_DEV void otz_k1_walk_loop(const otz_k1_lds &L, u32 lb, otz_k1_ws &W, u32 pen
 			// (row cnt / G, 512 bytes a row: cnt is a multiple of G here)
 			*reinterpret_cast<otz_ix_item *> (reinterpret_cast<u8 *> (rows) + ((cnt << 6) + lane8)) = k;
 		}
+#if OTZ_K1_SLIDE
+		const u32 wi = u >> 5;
+		const u32 *pw = reinterpret_cast<const u32 *> (reinterpret_cast<const u8 *> (L.win) + ((otz_opaque (wi) << 8) + lb));
+		const u32 w3 = pw[192], w4 = pw[256];
+		const otz_k1_step h = otz_k1_hot_w (L, w0, w1, w2, u);
+#else
 		const otz_k1_step h = otz_k1_hot (L, lb, u);
+#endif
 		const u32 tend = u + h.nb;
 		const bool bad = h.stop || tend > lim2;
 		const bool adv = !bad && !hit;
@@ -649,6 +671,15 @@ OTZ_DEV void otz_k1_walk_loop(const otz_k1_lds &L, u32 lb, otz_k1_ws &W, u32 pen
 			cnt += adv ? 1u : 0u;
 			u = hit ? u | OTZ_K1_MERGE : bad ? u | OTZ_K1_HALT : tend;
 		}
+#if OTZ_K1_SLIDE
+		{ // (a lane that leaves the loop slides by whatever its flag bits make of this: its words are dead)
+			const u32 dw = (u >> 5) - wi;
+			const bool d1 = dw == 1u, d2 = dw >= 2u;
+			w0 = d2 ? w2 : d1 ? w1 : w0;
+			w1 = d2 ? w3 : d1 ? w2 : w1;
+			w2 = d2 ? w4 : d1 ? w3 : w2;
+		}
+#endif
 	}
 	if (W.alive) {
 		W.bytes = bytes;

@@ -563,6 +563,7 @@ constexpr int MAX_DEV = 16;
 constexpr int N_SLOTS = 8; // asynchronous staged batches in flight per device (a full table is back-pressure for the caller: OZG_E_NOMEM)
 
 std::mutex g_mu; // contexts, their buffers and slots
+#define OTZ_AUX_STREAMS 4
 u32 g_chunks = 1; // chunks of a large DEFLATE batch on two internal streams (OTEZIP_GPU_CHUNKS; 0 = cut at a whole number of index-kernel generations): neither measured faster than one launch pair (4.13 ms; 4 chunks 4.43, generation cut 4.14), kept for experiments
 ozg_limits g_limits = { 1000ull, 1024ull * 1024ull };
 bool g_dbg_index_only = false; // diagnostics (OTEZIP_DEBUG_INDEX_ONLY=1): a DEFLATE batch stops behind its index kernel -- for timing experimental
@@ -619,8 +620,8 @@ struct workspace {
 	u32 *ovf = nullptr; // overflow list: count, then entry numbers
 	hipEvent_t done = nullptr;
 	bool busy = false;
-	hipStream_t aux[2] = { nullptr, nullptr };
-	hipEvent_t fork = nullptr, join[2] = { nullptr, nullptr };
+	hipStream_t aux[OTZ_AUX_STREAMS] = {};
+	hipEvent_t fork = nullptr, join[OTZ_AUX_STREAMS] = {};
 	// Zstandard: literal scratch of the persistent grid, its entry counter, the routing bytes
 	u8 *zs_lit = nullptr;
 	u32 zs_grid = 0;
@@ -758,7 +759,7 @@ int ws_reserve(workspace &ws, uint64_t src_len, uint64_t dst_len, uint32_t n) {
 	}
 	if (!ws.fork) {
 		OZG_HIP (hipEventCreateWithFlags (&ws.fork, hipEventDisableTiming));
-		for (int k = 0; k < 2; k++) {
+		for (int k = 0; k < OTZ_AUX_STREAMS; k++) {
 			OZG_HIP (hipStreamCreateWithFlags (&ws.aux[k], hipStreamNonBlocking));
 			OZG_HIP (hipEventCreateWithFlags (&ws.join[k], hipEventDisableTiming));
 		}
@@ -810,7 +811,7 @@ void ws_free(workspace &ws) {
 	}
 	if (ws.fork) {
 		(void)hipEventDestroy (ws.fork);
-		for (int k = 0; k < 2; k++) {
+		for (int k = 0; k < OTZ_AUX_STREAMS; k++) {
 			(void)hipStreamDestroy (ws.aux[k]);
 			(void)hipEventDestroy (ws.join[k]);
 		}
@@ -868,7 +869,7 @@ int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, 
 			OZG_HIP (hipGetLastError ());
 		} else {
 			OZG_HIP (hipEventRecord (ws.fork, s));
-			for (int k = 0; k < 2; k++) {
+			for (int k = 0; k < OTZ_AUX_STREAMS; k++) {
 				OZG_HIP (hipStreamWaitEvent (ws.aux[k], ws.fork, 0));
 			}
 			for (u32 c = 0; c < n_chunks; c++) {
@@ -877,7 +878,7 @@ int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, 
 					e0 = c ? cut : 0u;
 					e1 = c ? n : cut;
 				}
-				hipStream_t cs = ws.aux[c & 1u];
+				hipStream_t cs = ws.aux[c % OTZ_AUX_STREAMS];
 				hipLaunchKernelGGL (otz_index_kernel, dim3 (e1 - e0), dim3 (64), sizeof (otz_k1_lds), cs, (const u8 *)d_src, (u8 *)d_dst, d_entries, e0, n,
 					(u64)src_len, (u64)dst_len, g_limits, ws.arena, ws.regions, ws.heads, ws.ovf, g_prof);
 				OZG_HIP (hipGetLastError ());
@@ -887,7 +888,7 @@ int launch_decode(dev_ctx &C, const void *d_src, uint64_t src_len, void *d_dst, 
 				hipLaunchKernelGGL (otz_out_crc_kernel, dim3 (e1 - e0), dim3 (256), sizeof (otz_copy_lds), cs, (const u8 *)d_dst, d_entries, d_results, e0, n);
 				OZG_HIP (hipGetLastError ());
 			}
-			for (int k = 0; k < 2; k++) {
+			for (int k = 0; k < OTZ_AUX_STREAMS; k++) {
 				OZG_HIP (hipEventRecord (ws.join[k], ws.aux[k]));
 				OZG_HIP (hipStreamWaitEvent (s, ws.join[k], 0));
 			}

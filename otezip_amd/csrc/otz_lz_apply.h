@@ -57,6 +57,9 @@ static_assert (OTZ_A_RES_LANES <= OTZ_A_NT && OTZ_A_RES_LANES % 64u == 0, "whole
 #ifndef OTZ_A_RES_EAGER
 #define OTZ_A_RES_EAGER 0 // the resolution loop reads a step's source bytes together with their final bits
 #endif
+#ifndef OTZ_A_SLIDE
+#define OTZ_A_SLIDE 0 // 1: the placement loop carries its stage words from step to step (measured: no faster)
+#endif
 #ifndef OTZ_A_PLACE_V2
 #define OTZ_A_PLACE_V2 0 // the placement loop with one exit and the distance looked up for every lane (measured: no faster)
 #endif
@@ -373,12 +376,30 @@ OTZ_DEV u32 otz_place_items(otz_apply_lds &L, bool active, u32 s_bit, u32 e_bit,
 	u32 err = 0;                        // 1: the index and the stream disagree, 2: distance beyond the output start
 	u32 pos = s_bit;
 	if (active) {
+#if OTZ_A_SLIDE
+		// The three stage words of the token at pos are carried from step to step (a token is at most 48 bits: the
+		// next one starts in the same word or one of the next two); the two words that may slide in are asked for
+		// before the step's table lookups, so a step waits for its entries, not for the words and then the entries.
+		u32 w0, w1, w2;
+		{
+			const u32 *wp = &L.stage_w[otz_opaque (pos >> 5)];
+			w0 = wp[0];
+			w1 = wp[1];
+			w2 = wp[2];
+		}
+#endif
 		for (u32 i = 0; i < OTZ_IX_G; i++) {
 			if (pos >= e_bit) {
 				break;
 			}
+#if OTZ_A_SLIDE
+			const u32 wi = pos >> 5;
+			const u32 *wp = &L.stage_w[otz_opaque (wi)];
+			const u32 w3 = wp[3], w4 = wp[4]; // (inside the stage buffer: bit_room leaves 192 bits behind the round's last token)
+#else
 			const u32 *wp = &L.stage_w[otz_opaque (pos >> 5)];
 			const u32 w0 = wp[0], w1 = wp[1], w2 = wp[2];
+#endif
 			const u32 lo = otz_alignbit (w1, w0, pos), hi = otz_alignbit (w2, w1, pos);
 			const u32 e = otz_lut2<OTZ_LIT_ROOT> (L.lit_lut, lo);
 			const u32 len = e & 15u, kind = (e >> 4) & 3u;
@@ -419,6 +440,15 @@ OTZ_DEV u32 otz_place_items(otz_apply_lds &L, bool active, u32 s_bit, u32 e_bit,
 				err = 1;
 				break;
 			}
+#if OTZ_A_SLIDE
+			{
+				const u32 dw = (pos >> 5) - wi;
+				const bool d1 = dw == 1u, d2 = dw >= 2u;
+				w0 = d2 ? w2 : d1 ? w1 : w0;
+				w1 = d2 ? w3 : d1 ? w2 : w1;
+				w2 = d2 ? w4 : d1 ? w3 : w2;
+			}
+#endif
 		}
 		if (err == 0 && pos != e_bit) {
 			err = 1;
