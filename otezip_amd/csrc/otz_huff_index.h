@@ -569,6 +569,15 @@ OTZ_DEV const otz_ix_item *otz_k1_row(const otz_ix_item *rows, u32 r, u32 lane8)
 	return reinterpret_cast<const otz_ix_item *> (reinterpret_cast<const u8 *> (rows) + ((r << 9) + lane8));
 }
 
+#ifdef OTZ_K1_EXP
+OTZ_DEV u32 otz_wave_max_u32(u32 v) { // (diagnostics only)
+	for (u32 d = 1; d < 64u; d <<= 1) {
+		const u32 x = otz_shfl_xor (v, d);
+		v = x > v ? x : v;
+	}
+	return v;
+}
+#endif
 // State of a walk (registers), carried from piece to piece of the lane's segment.
 struct otz_k1_ws {
 	u32 u;       // slot-relative bit position: start of the next token
@@ -582,6 +591,9 @@ struct otz_k1_ws {
 	u32 first;   // walk A: where its chain starts (the first token start at or behind s, or where it started over)
 	u32 c, cpos; // walk B: walk A's next checkpoint at or behind u
 	u32 exit;    // exit word once the walk has ended
+#ifdef OTZ_K1_EXP
+	u32 steps;   // (diagnostics: trips of the walk loops)
+#endif
 };
 
 // One piece of a walk: the lanes with W.alive take tokens while they stand in front of `pend`.
@@ -623,6 +635,9 @@ OTZ_DEV void otz_k1_walk_loop(const otz_k1_lds &L, u32 lb, otz_k1_ws &W, u32 pen
 	otz_k1_words (L, lb, u < pend ? u : pend - 1u, w0, w1, w2); // (a lane that stays out of the loop: any word of the piece)
 #endif
 	while (u < pend && cnt < ncap) {
+#ifdef OTZ_K1_EXP
+		W.steps++;
+#endif
 		bool hit = false;
 		if (!SPEC) {
 			while (W.cpos < u) { // (rare: passed a checkpoint of walk A without landing on it)
@@ -644,7 +659,14 @@ OTZ_DEV void otz_k1_walk_loop(const otz_k1_lds &L, u32 lb, otz_k1_ws &W, u32 pen
 			k.bit = u;
 			k.out = bytes;
 			// (row cnt / G, 512 bytes a row: cnt is a multiple of G here)
+#if defined(OTZ_K1_EXP) && (OTZ_K1_EXP & 1)
+			if (!SPEC) // (timing experiment: walk A notes nothing)
+#endif
+#if defined(OTZ_K1_EXP) && (OTZ_K1_EXP & 2)
+			*reinterpret_cast<otz_ix_item *> (reinterpret_cast<u8 *> (rows) + (SPEC ? lane8 : (cnt << 6) + lane8)) = k; // (timing experiment: walk A writes one row)
+#else
 			*reinterpret_cast<otz_ix_item *> (reinterpret_cast<u8 *> (rows) + ((cnt << 6) + lane8)) = k;
+#endif
 		}
 #if OTZ_K1_SLIDE
 		const u32 wi = u >> 5;
@@ -757,6 +779,9 @@ OTZ_DEV void otz_k1_walk(otz_k1_lds &L, const u8 *in, u32 n_in, u32 rb, u32 sb, 
 	W.c = 1; // walk B: walk A's next checkpoint at or behind u (row 0 is its first token: bmA has it)
 	W.cpos = OTZ_K1_NONE;
 	W.exit = OTZ_X_MAKE (OTZ_X_INVALID, W.u);
+#ifdef OTZ_K1_EXP
+	W.steps = 0;
+#endif
 	if (!SPEC) {
 		W.cpos = run && nckA > 1u ? otz_k1_row (rowsA, 1u, 8u * otz_opaque (lane))->bit : OTZ_K1_NONE;
 	}
@@ -781,6 +806,9 @@ OTZ_DEV void otz_k1_walk(otz_k1_lds &L, const u8 *in, u32 n_in, u32 rb, u32 sb, 
 			// the warm-up: nothing is counted or noted, and a guess that runs into a code it cannot take moves on a bit
 			u32 u = W.u;
 			while (u < s) {
+#ifdef OTZ_K1_EXP
+				W.steps++;
+#endif
 				const otz_k1_step h = otz_k1_hot (L, lb, u);
 				const u32 tend = u + h.nb;
 				u = tend > lim2 ? u | OTZ_K1_HALT : h.stop ? u + 1u : tend;
@@ -868,6 +896,9 @@ template <bool PROF>
 OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap, bool out_aligned, u8 *region, u32 region_bytes, otz_ix_head *head, u64 *prof = nullptr) {
 	const u32 lane = otz_lane ();
 	u64 pc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+#ifdef OTZ_K1_EXP
+	u32 exp_steps[2] = { 0, 0 };
+#endif
 	u64 plast = PROF ? otz_cycles () : 0;
 	const u64 pstart = plast;
 	const u64 total_bits = (u64)n_in * 8u;
@@ -1036,6 +1067,9 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 			u32 firstA = OTZ_K1_NONE, dummy0 = 0, dummy1 = 0;
 			otz_k1_walk<true> (L, in, n_in, rb, S / 8u, A, true, lane ? s - OTZ_K1_WARM : s, s, e, rowsA_cap * OTZ_IX_G, rowsA, rowsA, 0, 0, 0, &firstA, &dummy0, &dummy1);
 			const u32 nckA = (A.cnt + OTZ_IX_G - 1u) / OTZ_IX_G; // checkpoint rows in front of tokens walk A took
+#ifdef OTZ_K1_EXP
+			exp_steps[0] += otz_wave_max_u32 (A.steps);
+#endif
 			OTZ_K1_MARK (3);
 			// ---- fixpoint over the true starts.  A lane's true path: nB tokens of its own walk B
 			// (none when it starts on walk A's first token), then -- if it lands on walk A's path at
@@ -1060,6 +1094,9 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 					otz_k1_ws W;
 					u32 unused = 0, j = 0, ob = 0;
 					otz_k1_walk<false> (L, in, n_in, rb, S / 8u, W, rewalk, nt, s, e, rowsB_cap * OTZ_IX_G, rowsB, rowsA, A.bm, nckA, firstA, &unused, &j, &ob);
+#ifdef OTZ_K1_EXP
+					exp_steps[1] += otz_wave_max_u32 (W.steps);
+#endif
 					if (rewalk) {
 						const bool early = W.merged && W.cpos != W.u;
 						nB = W.cnt;
@@ -1325,6 +1362,10 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 		prof[10] = pstart; // (timeline diagnostics: start, end, place)
 		prof[11] = otz_cycles ();
 		prof[12] = otz_where ();
+#ifdef OTZ_K1_EXP
+		prof[13] = exp_steps[0];
+		prof[14] = exp_steps[1];
+#endif
 		prof[15] = prof[11] - pstart;
 	}
 	return status == OTZ_IX_OVERFLOW;

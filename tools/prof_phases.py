@@ -70,6 +70,8 @@ def main():
         else:
             print("%-10s %10.0f cyc  %5.1f%%" % (name, m, 100 * m / tot1))
     print("%-10s %10.0f cyc" % ("total", tot1))
+    if k1[:, 13].any():  # (experiment builds -DOTZ_K1_EXP=...: trips of the walk loops per entry)
+        print("stepsA#    %10.1f\nstepsB#    %10.1f" % (k1[:, 13].mean(), k1[:, 14].mean()))
     oz.shutdown()
 
 
