@@ -99,9 +99,10 @@ struct otz_k1_lds {
 		} h;
 	};
 	// (behind the window: the walk's look-ahead reads two rows past it and ignores what it gets)
-	u16 lit[OTZ_K1_LLUT];
-	u16 dist[OTZ_K1_DLUT];
+	u16 lit[OTZ_K1_LLUT + OTZ_K1_DLUT]; // the literal/length table, then the distance table (OTZ_K1_DIST): one array,
+	                                    // so that a step's SECOND lookup is one load whichever table it goes to
 };
+#define OTZ_K1_DIST(L) ((L).lit + OTZ_K1_LLUT)
 static_assert (OTZ_K1_LLUT * 2u >= 2u * 256u, "two window rows of look-ahead stay inside the LDS block");
 static_assert (OTZ_K1_P != 512u || sizeof (otz_k1_lds) <= 6u * 1280u, "twenty wavefronts per CU: six 1280-byte granules of LDS each");
 
@@ -328,13 +329,13 @@ OTZ_DEV int otz_k1_build_tables(otz_k1_lds &L, u32 hlit, u32 hdist) {
 		reinterpret_cast<u32 *> (L.lit)[i] = OTZ_K1_SPECIAL * 0x10001u; // no code
 	}
 	for (u32 i = lane; i < OTZ_K1_DLUT / 2u; i += 64u) {
-		reinterpret_cast<u32 *> (L.dist)[i] = OTZ_K1_DBAD * 0x10001u;
+		reinterpret_cast<u32 *> (OTZ_K1_DIST (L))[i] = OTZ_K1_DBAD * 0x10001u;
 	}
 	int st = 0;
 	for (u32 tbl = 0; tbl < 2u; tbl++) {
 		const u32 nsym = tbl ? hdist : hlit, at0 = tbl ? hlit : 0u;
 		const u32 root = tbl ? OTZ_K1_DROOT : OTZ_K1_LROOT, rsz = 1u << root, cap = tbl ? OTZ_K1_DLUT : OTZ_K1_LLUT;
-		u16 *const lut = tbl ? L.dist : L.lit;
+		u16 *const lut = tbl ? OTZ_K1_DIST (L) : L.lit;
 		for (u32 i = lane; i < rsz / 4u; i += 64u) {
 			reinterpret_cast<u32 *> (L.h.subw)[i] = 0;
 		}
@@ -481,9 +482,9 @@ OTZ_DEV otz_k1_tok otz_k1_decode_bits(const otz_k1_lds &L, u32 lo, u32 hi) {
 	}
 	const u32 used = len + xb;
 	const u32 db = otz_alignbit (hi, lo, used);
-	u32 d = L.dist[db & ((1u << OTZ_K1_DROOT) - 1u)];
+	u32 d = OTZ_K1_DIST (L)[db & ((1u << OTZ_K1_DROOT) - 1u)];
 	if (d & 0x8000u) {
-		d = L.dist[(1u << OTZ_K1_DROOT) + ((d >> 4) & 0x7FFu) + otz_bfe (db, OTZ_K1_DROOT, d & 15u)];
+		d = OTZ_K1_DIST (L)[(1u << OTZ_K1_DROOT) + ((d >> 4) & 0x7FFu) + otz_bfe (db, OTZ_K1_DROOT, d & 15u)];
 	}
 	const bool is_len = B > 2u;
 	t.nbits = is_len ? used + d : len;
@@ -510,16 +511,30 @@ OTZ_DEV otz_k1_tok otz_k1_decode(const otz_k1_lds &L, u32 lb, u32 u) {
 }
 
 // The step of the walks' loops: window words (2 VALU for the address), 2 funnel shifts, literal/length
-// lookup, field extractions, funnel shift + distance lookup, the token's bits and bytes.  Straight-line but
-// for the rare second-level lookups: the distance entry is fetched for every lane (a literal reads some
-// entry and ignores it) -- a branch around it would cost more than the lookup and every step has both kinds.
+// lookup, field extractions, funnel shift + SECOND lookup, the step's bits and bytes.  Straight-line but
+// for the rare second-level lookups.  The second lookup is fetched for every lane and means what the first
+// one makes of it: behind a length code it is the distance entry (a branch around it would cost more than the
+// lookup and every step has both kinds); behind a literal it is the literal/length entry of the NEXT token, and
+// if that is a literal too the step takes both -- TWO LITERALS PER STEP.  That is not about the instruction
+// count: segments are equal in bits, a segment of literals holds three times the tokens of a segment of long
+// matches, and a walk lasts as long as its busiest lane -- the lanes that gain are the ones everybody waits
+// for (bench corpus, first block: busiest lane 433-458 steps -> 262-266, mean 256 -> 204).
+// allow: this step may take two (the caller keeps a pair from straddling a multiple of OTZ_IX_G tokens); bound: the
+// second literal starts in front of it (otz_k1_pair_bound of the end of the piece or segment, or of the start of the
+// segment in the warm-up: where a walk starts and where it leaves its segment are token starts its neighbours must
+// find it on; and a pair never ends beyond the limit).  A step that may not take two takes the first literal, as before.
 // stop: no token can be taken here (end of block, reserved symbol, no such code).
+#ifndef OTZ_K1_PAIRS
+#define OTZ_K1_PAIRS 1
+#endif
 struct otz_k1_step {
-	u32 nb;   // bits of the token; beyond every limit when its distance code is reserved
+	u32 nb;   // bits of the step; beyond every limit when its distance code is reserved
 	u32 ob;   // bytes it yields
+	u32 l1;   // two literals: bits of the first
 	bool stop;
+	bool pair; // two literals
 };
-OTZ_DEV otz_k1_step otz_k1_hot_w(const otz_k1_lds &L, u32 w0, u32 w1, u32 w2, u32 u) {
+OTZ_DEV otz_k1_step otz_k1_hot_w(const otz_k1_lds &L, u32 w0, u32 w1, u32 w2, u32 u, bool allow, u32 bound) {
 	const u32 lo = otz_alignbit (w1, w0, u), hi = otz_alignbit (w2, w1, u);
 	u32 e = L.lit[lo & ((1u << OTZ_K1_LROOT) - 1u)];
 	u32 xb = otz_bfe (e, 4, 3);
@@ -531,21 +546,44 @@ OTZ_DEV otz_k1_step otz_k1_hot_w(const otz_k1_lds &L, u32 w0, u32 w1, u32 w2, u3
 	r.stop = xb == 7u;
 	const u32 len = e & 15u, used = len + xb;
 	const u32 db = otz_alignbit (hi, lo, used);
-	u32 d = L.dist[db & ((1u << OTZ_K1_DROOT) - 1u)];
-	otz_touch32 (d); // (fetched here, for every lane)
 	const u32 B = e >> 7;
 	const bool is_len = B > 2u;
+#if OTZ_K1_PAIRS
+	u32 d = L.lit[is_len ? OTZ_K1_LLUT + (db & ((1u << OTZ_K1_DROOT) - 1u)) : db & ((1u << OTZ_K1_LROOT) - 1u)];
+#else
+	u32 d = OTZ_K1_DIST (L)[db & ((1u << OTZ_K1_DROOT) - 1u)];
+#endif
+	otz_touch32 (d); // (fetched here, for every lane)
 	if (is_len && (d & 0x8000u) != 0) { // rare: a distance code longer than the root
-		d = L.dist[(1u << OTZ_K1_DROOT) + ((d >> 4) & 0x7FFu) + otz_bfe (db, OTZ_K1_DROOT, d & 15u)];
+		d = OTZ_K1_DIST (L)[(1u << OTZ_K1_DROOT) + ((d >> 4) & 0x7FFu) + otz_bfe (db, OTZ_K1_DROOT, d & 15u)];
 	}
+#if OTZ_K1_PAIRS
+	// (a literal is X = 0, B = 1: the entry is 0x80 | code length -- for the first and for the second)
+	// (bitwise, not &&: the conditions are all computed, nothing branches)
+	r.l1 = len;
+	const u32 l2 = d & 15u;
+	const bool two = ((e | (d << 16)) & 0xFFF0FFF0u) == 0x00800080u;
+	r.pair = (bool) ((int)allow & (int)two & (int) (u + len < bound));
+	r.nb = used + (is_len ? d : r.pair ? l2 : 0u);
+	r.ob = B + otz_bfe (lo, len, xb) + (r.pair ? 1u : 0u);
+#else
+	r.l1 = len;
+	r.pair = false;
 	r.nb = used + (is_len ? d : 0u);
 	r.ob = B + otz_bfe (lo, len, xb);
+#endif
 	return r;
 }
-OTZ_DEV otz_k1_step otz_k1_hot(const otz_k1_lds &L, u32 lb, u32 u) {
+OTZ_DEV otz_k1_step otz_k1_hot(const otz_k1_lds &L, u32 lb, u32 u, bool allow, u32 bound) {
 	u32 w0, w1, w2;
 	otz_k1_words (L, lb, u, w0, w1, w2);
-	return otz_k1_hot_w (L, w0, w1, w2, u);
+	return otz_k1_hot_w (L, w0, w1, w2, u, allow, bound);
+}
+// Where a step's second literal has to start in front of: `bound`, and far enough from the limit for any literal code
+// (15 bits) to end inside it -- one comparison in the step instead of two.
+OTZ_DEV u32 otz_k1_pair_bound(u32 bound, u32 lim2) {
+	const u32 safe = lim2 >= 15u ? lim2 - 15u : 0u;
+	return bound < safe ? bound : safe;
 }
 
 // How a walk that stopped at slot-relative bit u (in front of e, inside the staged piece) ends: the exit word.
@@ -593,6 +631,7 @@ struct otz_k1_ws {
 	u32 exit;    // exit word once the walk has ended
 #ifdef OTZ_K1_EXP
 	u32 steps;   // (diagnostics: trips of the walk loops)
+	u32 loop_cyc; // (diagnostics: cycles inside the walk loops)
 #endif
 };
 
@@ -627,12 +666,22 @@ OTZ_DEV void otz_k1_walk_loop(const otz_k1_lds &L, u32 lb, otz_k1_ws &W, u32 pen
 	// bookkeeping): a chain that has come that far has met the real one, and what stops it then stops the block.
 	// (Whatever walk A does is a hint: the true path is walk B's, up to where it lands on walk A's chain.)
 	const bool may_restart = SPEC && YOUNG && otz_lane () != 0;
+#ifdef OTZ_K1_EXP
+	const u64 exp_t0 = otz_cycles ();
+#endif
 #if OTZ_K1_SLIDE
 	// The three window words of the token at u are carried from step to step: a token is at most 48 bits, so the
 	// next one starts in the same word or one of the next two, and the two words that may slide in are asked for
 	// BEFORE this step's lookups -- the step waits for its table entries, not for the window and then the entries.
 	u32 w0, w1, w2;
 	otz_k1_words (L, lb, u < pend ? u : pend - 1u, w0, w1, w2); // (a lane that stays out of the loop: any word of the piece)
+#endif
+	const u32 pbound = otz_k1_pair_bound (pend, lim2);
+#if OTZ_K1_PAIRS
+	otz_ix_item pk; // the lane's checkpoint that is not in memory yet
+	pk.bit = OTZ_K1_NONE;
+	pk.out = 0;
+	u32 trip = 0;
 #endif
 	while (u < pend && cnt < ncap) {
 #ifdef OTZ_K1_EXP
@@ -654,35 +703,69 @@ OTZ_DEV void otz_k1_walk_loop(const otz_k1_lds &L, u32 lb, otz_k1_ws &W, u32 pen
 			const u32 rel = u - s;
 			bm |= rel < 64u ? (u64)1 << rel : 0u;
 		}
+#if OTZ_K1_PAIRS
+		// With two literals in some steps the lanes' token counts drift apart and SOME lane stands on a multiple of
+		// OTZ_IX_G in nearly every trip: a store instruction per trip for a handful of lanes, and the vector-memory
+		// path of the CU is what 20 wavefronts doing that wait for.  So a checkpoint is kept in registers and the
+		// wavefront stores every fourth trip, all lanes that have one (a lane makes one every four trips at most --
+		// OTZ_IX_G tokens, two per trip -- and its count is still in the same row when it is stored).
+		if ((cnt & (OTZ_IX_G - 1u)) == 0) {
+			pk.bit = u;
+			pk.out = bytes;
+		}
+		if ((++trip & 3u) == 0) {
+			if (pk.bit != OTZ_K1_NONE) {
+				*reinterpret_cast<otz_ix_item *> (reinterpret_cast<u8 *> (rows) + (((cnt & ~(OTZ_IX_G - 1u)) << 6) + lane8)) = pk;
+				pk.bit = OTZ_K1_NONE;
+			}
+		}
+#else
 		if ((cnt & (OTZ_IX_G - 1u)) == 0) {
 			otz_ix_item k;
 			k.bit = u;
 			k.out = bytes;
 			// (row cnt / G, 512 bytes a row: cnt is a multiple of G here)
-#if defined(OTZ_K1_EXP) && (OTZ_K1_EXP & 1)
-			if (!SPEC) // (timing experiment: walk A notes nothing)
-#endif
-#if defined(OTZ_K1_EXP) && (OTZ_K1_EXP & 2)
-			*reinterpret_cast<otz_ix_item *> (reinterpret_cast<u8 *> (rows) + (SPEC ? lane8 : (cnt << 6) + lane8)) = k; // (timing experiment: walk A writes one row)
-#else
 			*reinterpret_cast<otz_ix_item *> (reinterpret_cast<u8 *> (rows) + ((cnt << 6) + lane8)) = k;
-#endif
 		}
+#endif
 #if OTZ_K1_SLIDE
 		const u32 wi = u >> 5;
 		const u32 *pw = reinterpret_cast<const u32 *> (reinterpret_cast<const u8 *> (L.win) + ((otz_opaque (wi) << 8) + lb));
 		const u32 w3 = pw[192], w4 = pw[256];
-		const otz_k1_step h = otz_k1_hot_w (L, w0, w1, w2, u);
+		otz_k1_step h = otz_k1_hot_w (L, w0, w1, w2, u, (cnt & (OTZ_IX_G - 1u)) != OTZ_IX_G - 1u, pbound);
 #else
-		const otz_k1_step h = otz_k1_hot (L, lb, u);
+		otz_k1_step h = otz_k1_hot (L, lb, u, (cnt & (OTZ_IX_G - 1u)) != OTZ_IX_G - 1u, pbound);
+#endif
+#if OTZ_K1_PAIRS
+		if (!SPEC) {
+			// walk B does not step over a position of walk A it could land on: the second literal's start
+			const u32 mid = u + h.l1;
+			bool on_a = mid == W.cpos;
+			if (EARLY) {
+				const u32 relm = mid - s;
+				on_a = on_a || (relm < 64u && ((bmA >> relm) & 1u) != 0);
+			}
+			if (h.pair && on_a) {
+				h.pair = false;
+				h.nb = h.l1;
+				h.ob = 1u;
+			}
+		}
 #endif
 		const u32 tend = u + h.nb;
 		const bool bad = h.stop || tend > lim2;
 		const bool adv = !bad && !hit;
+		const u32 ntok = OTZ_K1_PAIRS && h.pair ? 2u : 1u;
+#if OTZ_K1_PAIRS
+		if (SPEC && EARLY) { // the second literal of a pair is a token start of this chain like any other
+			const u32 relm = u + h.l1 - s;
+			bm |= h.pair && relm < 64u ? (u64)1 << relm : 0u;
+		}
+#endif
 		if (SPEC && YOUNG) {
 			const bool again = may_restart && h.stop && tend <= lim2;
 			bytes = again ? 0u : bytes + (adv ? h.ob : 0u);
-			cnt = again ? 0u : cnt + (adv ? 1u : 0u);
+			cnt = again ? 0u : cnt + (adv ? ntok : 0u);
 			first = again ? u + 1u : first;
 			if (EARLY) {
 				bm = again ? 0u : bm;
@@ -690,7 +773,7 @@ OTZ_DEV void otz_k1_walk_loop(const otz_k1_lds &L, u32 lb, otz_k1_ws &W, u32 pen
 			u = again ? u + 1u : bad ? u | OTZ_K1_HALT : tend;
 		} else {
 			bytes += adv ? h.ob : 0u;
-			cnt += adv ? 1u : 0u;
+			cnt += adv ? ntok : 0u;
 			u = hit ? u | OTZ_K1_MERGE : bad ? u | OTZ_K1_HALT : tend;
 		}
 #if OTZ_K1_SLIDE
@@ -703,6 +786,14 @@ OTZ_DEV void otz_k1_walk_loop(const otz_k1_lds &L, u32 lb, otz_k1_ws &W, u32 pen
 		}
 #endif
 	}
+#if OTZ_K1_PAIRS
+	if (pk.bit != OTZ_K1_NONE) { // (at most three steps old: the count is still in its row)
+		*reinterpret_cast<otz_ix_item *> (reinterpret_cast<u8 *> (rows) + (((cnt & ~(OTZ_IX_G - 1u)) << 6) + lane8)) = pk;
+	}
+#endif
+#ifdef OTZ_K1_EXP
+	W.loop_cyc += (u32) (otz_cycles () - exp_t0);
+#endif
 	if (W.alive) {
 		W.bytes = bytes;
 		W.cnt = cnt;
@@ -781,6 +872,7 @@ OTZ_DEV void otz_k1_walk(otz_k1_lds &L, const u8 *in, u32 n_in, u32 rb, u32 sb, 
 	W.exit = OTZ_X_MAKE (OTZ_X_INVALID, W.u);
 #ifdef OTZ_K1_EXP
 	W.steps = 0;
+	W.loop_cyc = 0;
 #endif
 	if (!SPEC) {
 		W.cpos = run && nckA > 1u ? otz_k1_row (rowsA, 1u, 8u * otz_opaque (lane))->bit : OTZ_K1_NONE;
@@ -805,11 +897,12 @@ OTZ_DEV void otz_k1_walk(otz_k1_lds &L, const u8 *in, u32 n_in, u32 rb, u32 sb, 
 		if (SPEC && k == 0) {
 			// the warm-up: nothing is counted or noted, and a guess that runs into a code it cannot take moves on a bit
 			u32 u = W.u;
+			const u32 wbound = otz_k1_pair_bound (s, lim2);
 			while (u < s) {
 #ifdef OTZ_K1_EXP
 				W.steps++;
 #endif
-				const otz_k1_step h = otz_k1_hot (L, lb, u);
+				const otz_k1_step h = otz_k1_hot (L, lb, u, true, wbound);
 				const u32 tend = u + h.nb;
 				u = tend > lim2 ? u | OTZ_K1_HALT : h.stop ? u + 1u : tend;
 			}
@@ -1069,6 +1162,7 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 			const u32 nckA = (A.cnt + OTZ_IX_G - 1u) / OTZ_IX_G; // checkpoint rows in front of tokens walk A took
 #ifdef OTZ_K1_EXP
 			exp_steps[0] += otz_wave_max_u32 (A.steps);
+			pc[2] += otz_wave_max_u32 (A.loop_cyc); // (reported as "slots": cycles inside walk A's loops)
 #endif
 			OTZ_K1_MARK (3);
 			// ---- fixpoint over the true starts.  A lane's true path: nB tokens of its own walk B
