@@ -632,6 +632,7 @@ struct otz_k1_ws {
 #ifdef OTZ_K1_EXP
 	u32 steps;   // (diagnostics: trips of the walk loops)
 	u32 loop_cyc; // (diagnostics: cycles inside the walk loops)
+	u32 stage_cyc; // (diagnostics: cycles staging pieces)
 #endif
 };
 
@@ -827,20 +828,66 @@ OTZ_DEV u32 otz_k1_limit(u32 n_in, u32 rb, u32 sb) {
 }
 
 // Stage piece k of every lane's slot: OTZ_K1_WROWS words from entry byte slot0 + k * P / 8 (zeros outside the
-// entry), each lane its own column of the window.
+// entry), each lane its own column of the window.  ALL the 16-byte loads are issued before any of them is waited
+// for: written the obvious way -- load a chunk, store it to LDS, next chunk -- every chunk is a global-memory round
+// trip of its own (each sits behind a bounds test), five in a row per piece, and under load that was 14 % of the
+// kernel's time.  The chunks that straddle an end of the entry (one lane, in few pieces) are patched afterwards.
 OTZ_DEV void otz_k1_stage_piece(otz_k1_lds &L, const u8 *in, u32 n_in, u32 rb, u32 sb, u32 k) {
 	const u32 lane = otz_lane ();
 	const int64_t b = otz_k1_slot0 (rb, sb) + (int64_t) (k * (OTZ_K1_P / 8u));
 	static_assert (OTZ_K1_WROWS % 4u == 2u, "whole 16-byte loads and half of one");
+	constexpr u32 NQ = (OTZ_K1_WROWS + 3u) / 4u;
+	otz_u4 v[NQ];
+	bool edge = false;
+	// (a chunk that does not lie inside the entry loads the entry's first bytes instead and is zeroed afterwards:
+	// a conditional load would have to wait for the ones in flight before its registers could be cleared)
+	const bool big = n_in >= 16u;
+	if (big) {
 #pragma unroll
-	for (u32 q = 0; q < (OTZ_K1_WROWS + 3u) / 4u; q++) {
-		const otz_u4 v = otz_k1_ld16 (in, n_in, b + 16 * (int64_t)q);
+		for (u32 q = 0; q < NQ; q++) {
+			const int64_t off = b + 16 * (int64_t)q;
+			const bool inside = off >= 0 && off + 16 <= (int64_t)n_in;
+			v[q] = otz_ld16 (in + (inside ? off : 0));
+		}
+	} else {
+#pragma unroll
+		for (u32 q = 0; q < NQ; q++) {
+			const otz_u4 zero = { 0, 0, 0, 0 };
+			v[q] = zero;
+		}
+	}
+#pragma unroll
+	for (u32 q = 0; q < NQ; q++) {
+		const int64_t off = b + 16 * (int64_t)q;
+		const bool inside = big && off >= 0 && off + 16 <= (int64_t)n_in;
+		edge = edge || (!inside && off + 16 > 0 && off < (int64_t)n_in);
+	}
+#pragma unroll
+	for (u32 q = 0; q < NQ; q++) {
+		const int64_t off = b + 16 * (int64_t)q;
+		const bool inside = big && off >= 0 && off + 16 <= (int64_t)n_in;
+		v[q].x = inside ? v[q].x : 0u;
+		v[q].y = inside ? v[q].y : 0u;
+		v[q].z = inside ? v[q].z : 0u;
+		v[q].w = inside ? v[q].w : 0u;
+	}
+	if (otz_ballot (edge) != 0) { // rare: some chunk holds an end of the entry
+#pragma unroll
+		for (u32 q = 0; q < NQ; q++) {
+			const int64_t off = b + 16 * (int64_t)q;
+			if (!(big && off >= 0 && off + 16 <= (int64_t)n_in) && off + 16 > 0 && off < (int64_t)n_in) {
+				v[q] = otz_k1_ld16 (in, n_in, off);
+			}
+		}
+	}
+#pragma unroll
+	for (u32 q = 0; q < NQ; q++) {
 		u32 *d = &L.win[(4u * q) * 64u + lane];
-		d[0] = v.x;
-		d[64] = v.y;
+		d[0] = v[q].x;
+		d[64] = v[q].y;
 		if (4u * q + 2u < OTZ_K1_WROWS) {
-			d[128] = v.z;
-			d[192] = v.w;
+			d[128] = v[q].z;
+			d[192] = v[q].w;
 		}
 	}
 }
@@ -873,6 +920,7 @@ OTZ_DEV void otz_k1_walk(otz_k1_lds &L, const u8 *in, u32 n_in, u32 rb, u32 sb, 
 #ifdef OTZ_K1_EXP
 	W.steps = 0;
 	W.loop_cyc = 0;
+	W.stage_cyc = 0;
 #endif
 	if (!SPEC) {
 		W.cpos = run && nckA > 1u ? otz_k1_row (rowsA, 1u, 8u * otz_opaque (lane))->bit : OTZ_K1_NONE;
@@ -891,9 +939,18 @@ OTZ_DEV void otz_k1_walk(otz_k1_lds &L, const u8 *in, u32 n_in, u32 rb, u32 sb, 
 		const u32 lb = 4u * lane - 256u * OTZ_K1_PW * k;
 		// (LDS only, and the LDS executes a wavefront's instructions in order: nothing has to drain -- in particular
 		// not the checkpoint stores, which stay in flight across pieces)
+#ifdef OTZ_K1_EXP
+#if OTZ_K1_EXP & 4
+		otz_wave_sync (); // (timing experiment: the checkpoint stores drain before the clock starts)
+#endif
+		const u64 exp_s0 = otz_cycles ();
+#endif
 		otz_wave_sync_lds (); // the previous piece (or the block prologue's scratch) is dead
 		otz_k1_stage_piece (L, in, n_in, rb, sb, k);
 		otz_wave_sync_lds ();
+#ifdef OTZ_K1_EXP
+		W.stage_cyc += (u32) (otz_cycles () - exp_s0);
+#endif
 		if (SPEC && k == 0) {
 			// the warm-up: nothing is counted or noted, and a guess that runs into a code it cannot take moves on a bit
 			u32 u = W.u;
@@ -1163,6 +1220,7 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 #ifdef OTZ_K1_EXP
 			exp_steps[0] += otz_wave_max_u32 (A.steps);
 			pc[2] += otz_wave_max_u32 (A.loop_cyc); // (reported as "slots": cycles inside walk A's loops)
+			exp_steps[1] += otz_wave_max_u32 (A.stage_cyc); // (reported as stepsB#: cycles staging walk A's pieces)
 #endif
 			OTZ_K1_MARK (3);
 			// ---- fixpoint over the true starts.  A lane's true path: nB tokens of its own walk B
@@ -1188,9 +1246,6 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 					otz_k1_ws W;
 					u32 unused = 0, j = 0, ob = 0;
 					otz_k1_walk<false> (L, in, n_in, rb, S / 8u, W, rewalk, nt, s, e, rowsB_cap * OTZ_IX_G, rowsB, rowsA, A.bm, nckA, firstA, &unused, &j, &ob);
-#ifdef OTZ_K1_EXP
-					exp_steps[1] += otz_wave_max_u32 (W.steps);
-#endif
 					if (rewalk) {
 						const bool early = W.merged && W.cpos != W.u;
 						nB = W.cnt;
