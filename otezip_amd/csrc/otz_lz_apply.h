@@ -60,6 +60,9 @@ static_assert (OTZ_A_RES_LANES <= OTZ_A_NT && OTZ_A_RES_LANES % 64u == 0, "whole
 #ifndef OTZ_A_SLIDE
 #define OTZ_A_SLIDE 0 // 1: the placement loop carries its stage words from step to step (measured: no faster)
 #endif
+#ifndef OTZ_A_ITEMS_AHEAD
+#define OTZ_A_ITEMS_AHEAD 1
+#endif
 #ifndef OTZ_A_PLACE_V2
 #define OTZ_A_PLACE_V2 0 // the placement loop with one exit and the distance looked up for every lane (measured: no faster)
 #endif
@@ -547,11 +550,11 @@ OTZ_DEV void otz_far_copies(otz_apply_lds &L, const otz_job &J, u32 p0, const u1
 				const u32 *gp = reinterpret_cast<const u32 *> ((uintptr_t)g & ~(uintptr_t)3);
 				q = (u32) (uintptr_t)g & 3u;
 				const u32 span = q + n; // 1..19: only the words that hold bytes of the source (they lie inside the entry's output)
-				s0 = gp[0];
-				s1 = span > 4u ? gp[1] : 0u;
-				s2 = span > 8u ? gp[2] : 0u;
-				s3 = span > 12u ? gp[3] : 0u;
-				s4 = span > 16u ? gp[4] : 0u;
+				s0 = otz_ldg32 (gp);
+				s1 = span > 4u ? otz_ldg32 (gp + 1) : 0u;
+				s2 = span > 8u ? otz_ldg32 (gp + 2) : 0u;
+				s3 = span > 12u ? otz_ldg32 (gp + 3) : 0u;
+				s4 = span > 16u ? otz_ldg32 (gp + 4) : 0u;
 			} else {
 				const u32 *sp = reinterpret_cast<const u32 *> (&L.rbuf[(u32)si & ~3u]);
 				q = (u32)si & 3u;
@@ -867,12 +870,27 @@ OTZ_DEV void otz_apply_entry(otz_apply_lds &L, const otz_job &J, const otz_ix_he
 		OTZ_MARK (L, J, OTZ_P_TABLES);
 		const otz_ix_item *items = reinterpret_cast<const otz_ix_item *> (region + boff + OTZ_IX_ITEMS_OFF);
 		u32 base = 0;
+#if OTZ_A_ITEMS_AHEAD
+		// the round's items are asked for a round ahead (behind the previous round's count, in front of its staging,
+		// placement and resolution): a round then waits for ONE trip to global memory, its compressed bytes
+		otz_ix_item a_n, z_n, first_n;
+		{
+			const u32 ia = tid < n_items ? tid : n_items;
+			a_n = items[ia];
+			z_n = items[ia < n_items ? ia + 1u : n_items];
+			first_n = items[0];
+		}
+#endif
 		while (base < n_items) {
 			// ---- how many items this round takes
+#if OTZ_A_ITEMS_AHEAD
+			const otz_ix_item a = a_n, z = z_n, first = first_n;
+#else
 			const u32 ia = base + tid < n_items ? base + tid : n_items;
 			const u32 ib = ia < n_items ? ia + 1u : n_items;
 			const otz_ix_item a = items[ia], z = items[ib];
 			const otz_ix_item first = items[base];
+#endif
 			const u64 abs0 = bit_base + first.bit;
 			const u32 byte0 = (u32) (abs0 >> 3);
 			const u32 skew = (u32) ((uintptr_t) (J.in + byte0) & 15u);
@@ -893,8 +911,17 @@ OTZ_DEV void otz_apply_entry(otz_apply_lds &L, const otz_job &J, const otz_ix_he
 				}
 			}
 			otz_sync ();
-			const u32 n = L.first_rej;
+			const u32 n = otz_uniform (L.first_rej);
 			const u32 span_bits = L.flag;
+#if OTZ_A_ITEMS_AHEAD
+			{
+				const u32 nb = base + n;
+				const u32 ia = nb + tid < n_items ? nb + tid : n_items;
+				a_n = items[ia];
+				z_n = items[ia < n_items ? ia + 1u : n_items];
+				first_n = items[nb < n_items ? nb : n_items];
+			}
+#endif
 #ifdef OTZ_ST_PROF
 			OTZ_MARK (L, J, 1);
 #endif

@@ -150,6 +150,12 @@ OTZ_DEV u32 otz_ld32u(const void *p) {
 	__builtin_memcpy (&v, p, 4);
 	return v;
 }
+// An aligned word of GLOBAL memory through a pointer the compiler no longer knows the address space of (one that
+// came out of a struct): said explicitly, it is a global_load; left generic it is a flat_load, which counts on the
+// LDS counter as well -- the next wait for an LDS access then waits for the global round trip too.
+OTZ_DEV u32 otz_ldg32(const void *p) {
+	return *reinterpret_cast<const __attribute__ ((address_space (1))) u32 *> (reinterpret_cast<uintptr_t> (p));
+}
 OTZ_DEV void otz_st64u(void *p, u64 v) { __builtin_memcpy (p, &v, 8); }
 OTZ_DEV void otz_st32u(void *p, u32 v) { __builtin_memcpy (p, &v, 4); }
 OTZ_DEV void otz_st16u(void *p, u16 v) { __builtin_memcpy (p, &v, 2); }

@@ -217,6 +217,7 @@ OTZ_DEV u32 otz_ld32u(const void *p) {
 	memcpy (&v, p, 4);
 	return v;
 }
+OTZ_DEV u32 otz_ldg32(const void *p) { return *reinterpret_cast<const u32 *> (p); }
 OTZ_DEV void otz_st64u(void *p, u64 v) { memcpy (p, &v, 8); }
 OTZ_DEV void otz_st32u(void *p, u32 v) { memcpy (p, &v, 4); }
 OTZ_DEV void otz_st16u(void *p, u16 v) { memcpy (p, &v, 2); }
