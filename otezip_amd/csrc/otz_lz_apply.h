@@ -60,6 +60,9 @@ static_assert (OTZ_A_RES_LANES <= OTZ_A_NT && OTZ_A_RES_LANES % 64u == 0, "whole
 #ifndef OTZ_A_SLIDE
 #define OTZ_A_SLIDE 0 // 1: the placement loop carries its stage words from step to step (measured: no faster)
 #endif
+#ifndef OTZ_A_DECIDE_AHEAD
+#define OTZ_A_DECIDE_AHEAD 1 // a round's size is decided a round ahead (two barriers fewer per round)
+#endif
 #ifndef OTZ_A_ITEMS_AHEAD
 #define OTZ_A_ITEMS_AHEAD 1
 #endif
@@ -90,6 +93,7 @@ struct otz_apply_lds {
 	u32 flag;
 	u32 first_rej;
 	u32 last_out;
+	u32 dec[2][2]; // the round-size decision a round ahead, two slots in turn: [0] first item that does not fit, [1] bits of the round
 	u32 dbg[4];
 	u64 prof_last;
 	u64 prof[16];
@@ -794,6 +798,25 @@ OTZ_DEV u8 otz_a_byte(const otz_apply_lds &L, const otz_job &J, const otz_a_pos 
 	return p < P.p0 ? J.out[p] : L.rbuf[p - P.p0];
 }
 
+// The verdict on the items base, base + 1, ... of a block as one round (lane j: item base + j, a / z its start and
+// end, first the round's first item): dec[0] = the first lane whose item no longer fits (the round's output within
+// OTZ_A_RMAX, its bits within the stage buffer), dec[1] = the bits of the items in front of it.  All work-items;
+// dec was reset a barrier ago and is read a barrier later.
+OTZ_DEV void otz_a_decide(otz_apply_lds &L, const otz_job &J, u32 *dec, u64 bit_base, u32 base, u32 n_items, otz_ix_item a, otz_ix_item z, otz_ix_item first) {
+	const u64 abs0 = bit_base + first.bit;
+	const u32 byte0 = (u32) (abs0 >> 3);
+	const u32 skew = (u32) ((uintptr_t) (J.in + byte0) & 15u);
+	const u32 p0 = skew * 8u + (u32) (abs0 & 7u);
+	// a walk reads up to five words past the one holding its position
+	const u32 bit_room = 8u * OTZ_A_STAGE_BYTES - 192u - p0;
+	const bool fits = base + otz_tid () < n_items && z.out - first.out <= OTZ_A_RMAX && z.bit - first.bit <= bit_room && z.out >= a.out && z.bit >= a.bit;
+	otz_wave_min_tid (&dec[0], !fits);
+	const u64 fm = otz_ballot (fits);
+	if (fm != 0 && otz_lane () == 63u - otz_clz64 (fm)) { // (the last fitting lane of each wavefront knows how far the bits reach)
+		otz_lds_max (&dec[1], z.bit - first.bit);
+	}
+}
+
 // All OTZ_A_NT work-items.  Work-item 0 writes *res (crc32 and the CRC flag are left to the CRC pass).
 // end_bit (optional): where the stream ended, for the z_stream seam's total_in.
 OTZ_DEV void otz_apply_entry(otz_apply_lds &L, const otz_job &J, const otz_ix_head *head, const u8 *region, ozg_result *res, u64 *end_bit) {
@@ -869,6 +892,102 @@ OTZ_DEV void otz_apply_entry(otz_apply_lds &L, const otz_job &J, const otz_ix_he
 		}
 		OTZ_MARK (L, J, OTZ_P_TABLES);
 		const otz_ix_item *items = reinterpret_cast<const otz_ix_item *> (region + boff + OTZ_IX_ITEMS_OFF);
+#if OTZ_A_DECIDE_AHEAD
+		// How many items a round takes is decided A ROUND AHEAD: the next round's items are asked for at the top of a
+		// round, their verdict (the first item that does not fit the round buffer or the stage buffer) goes into one of
+		// two LDS slots in front of the resolution loop and is read behind the barrier that closes it -- a barrier the
+		// round has anyway.  Decided at the top of its own round it cost two barriers and an exposed trip to global
+		// memory per round, with 32 wavefronts per CU waiting for issue slots at every barrier.
+		u32 base = 0, par = 0;
+		otz_ix_item a, z, first;
+		{
+			const u32 ia = tid < n_items ? tid : n_items;
+			a = items[ia];
+			z = items[ia < n_items ? ia + 1u : n_items];
+			first = items[0];
+		}
+		if (tid == 0) {
+			L.dec[0][0] = OTZ_A_NT;
+			L.dec[0][1] = 0;
+		}
+		otz_sync ();
+		otz_a_decide (L, J, L.dec[0], bit_base, base, n_items, a, z, first);
+		otz_sync ();
+		u32 n = otz_uniform (L.dec[0][0]), span_bits = L.dec[0][1];
+		while (base < n_items) {
+			const u64 abs0 = bit_base + first.bit;
+			const u32 byte0 = (u32) (abs0 >> 3);
+			const u32 skew = (u32) ((uintptr_t) (J.in + byte0) & 15u);
+			const u32 p0 = skew * 8u + (u32) (abs0 & 7u);
+			if (n == 0 || blk->out_base + first.out != P.opos) {
+				otz_fail_all (L, OZG_ST_INTERNAL);
+				break;
+			}
+			// ---- the next round's items
+			const u32 nb = base + n;
+			otz_ix_item a_n, z_n, first_n;
+			{
+				const u32 ia = nb + tid < n_items ? nb + tid : n_items;
+				a_n = items[ia];
+				z_n = items[ia < n_items ? ia + 1u : n_items];
+				first_n = items[nb < n_items ? nb : n_items];
+			}
+			if (tid + 1u == n) {
+				L.last_out = z.out; // (read after the barriers of otz_place_items)
+			}
+			if (tid == 0) { // the slot of the next decision (its last readers passed the barrier that ended the previous round)
+				L.dec[par ^ 1u][0] = OTZ_A_NT;
+				L.dec[par ^ 1u][1] = 0;
+			}
+#ifdef OTZ_ST_PROF
+			OTZ_MARK (L, J, 1);
+#endif
+			otz_a_stage (L, J, byte0, (((u32)abs0 & 7u) + span_bits + 7u) / 8u + 24u);
+#ifdef OTZ_ST_PROF
+			OTZ_MARK (L, J, 6);
+#endif
+			otz_a_begin (L, P);
+			otz_sync ();
+			OTZ_MARK (L, J, OTZ_P_STAGE);
+			OTZ_COUNT (L, J, OTZ_P_ROUNDS, 1);
+			const u32 s_bit = p0 + (a.bit - first.bit), e_bit = p0 + (z.bit - first.bit);
+			// the match list takes over the stage buffer once every lane has read its tokens
+			u16 *const list = reinterpret_cast<u16 *> (L.stage);
+			u32 n_far = 0;
+			const u32 n_matches = otz_place_items (L, tid < n, s_bit, e_bit, P.opos - P.p0 + (a.out - first.out), P.p0, list, &n_far);
+			otz_sync ();
+			OTZ_MARK (L, J, OTZ_P_EMIT);
+			if (otz_get_status (L) != 0) {
+				break;
+			}
+			otz_far_copies (L, J, P.p0, list, n_far);
+			otz_a_decide (L, J, L.dec[par ^ 1u], bit_base, nb, n_items, a_n, z_n, first_n);
+#if OTZ_A_RES_PRIO
+			otz_set_priority_high (); // (the resolution loop goes first, the bulk phases of the other workgroups fill the gaps)
+#endif
+			if (OTZ_A_RES_LANES == OTZ_A_NT || tid < OTZ_A_RES_LANES) {
+				otz_resolve_list (L, J, list, n_matches);
+			}
+#if OTZ_A_RES_PRIO
+			otz_set_priority_normal ();
+#endif
+			otz_sync ();
+			OTZ_MARK (L, J, OTZ_P_RESOLVE);
+			if (otz_get_status (L) != 0) {
+				break;
+			}
+			const u32 n_next = otz_uniform (L.dec[par ^ 1u][0]), span_next = L.dec[par ^ 1u][1];
+			otz_a_advance (L, J, P, L.last_out - first.out);
+			OTZ_MARK (L, J, OTZ_P_FLUSH);
+			base = nb;
+			a = a_n;
+			z = z_n;
+			first = first_n;
+			n = n_next;
+			span_bits = span_next;
+			par ^= 1u;
+		}
+#else
 		u32 base = 0;
 #if OTZ_A_ITEMS_AHEAD
 		// the round's items are asked for a round ahead (behind the previous round's count, in front of its staging,
@@ -969,6 +1088,7 @@ OTZ_DEV void otz_apply_entry(otz_apply_lds &L, const otz_job &J, const otz_ix_he
 			OTZ_MARK (L, J, OTZ_P_FLUSH);
 			base += n;
 		}
+#endif
 		boff = next;
 	}
 
