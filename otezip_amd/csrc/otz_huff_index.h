@@ -38,7 +38,10 @@
 #ifndef OTZ_K1_P
 #define OTZ_K1_P 512u     // bits of its segment a lane stages per piece
 #endif
-#define OTZ_K1_WARM 128u  // head start of walk A (bits)
+#ifndef OTZ_K1_WARM
+#define OTZ_K1_WARM 256u  // head start of walk A (bits; a multiple of 8).  Measured, index kernel at full occupancy: 64 bits 0.82 ms, 96 0.90,
+                          // 128 0.89, 192 0.80, 256 0.79-0.80, 320 0.80, 384 0.78-0.79, 440 0.79 (re-walk passes per entry 2.8 ... 1.7)
+#endif
 #define OTZ_K1_PW (OTZ_K1_P / 32u)    // words of a piece
 #define OTZ_K1_WROWS (OTZ_K1_PW + 2u) // window rows (words per lane): the piece and the reach of a token that starts on its
                                       // last bit (two words more).  With 512-bit pieces the wavefront's LDS is 7680 bytes: the
@@ -46,7 +49,7 @@
                                       // six of them is the most that leaves room for twenty wavefronts
 #define OTZ_K1_HDR_WORDS 264u // staged bytes for a block header: 17 + 57 + 318 x 14 bits < 1056 bytes
 
-static_assert (OTZ_K1_P % 128u == 0 && OTZ_K1_P >= 256u && OTZ_K1_WARM == 128u, "a piece is a whole number of 16-byte loads; the warm-up and the early token starts lie in the first piece");
+static_assert (OTZ_K1_P % 128u == 0 && OTZ_K1_P >= 256u && OTZ_K1_WARM % 8u == 0 && OTZ_K1_WARM + 7u + 64u <= OTZ_K1_P, "a piece is a whole number of 16-byte loads; the warm-up and the early token starts lie in the first piece");
 static_assert (OTZ_K1_SMIN % 32u == 0 && OTZ_K1_SMAX % 32u == 0 && OTZ_K1_WARM + 7u + OTZ_K1_SMAX + 48u < (1u << 24), "segments are whole words; positions fit the exit word");
 static_assert ((OTZ_IX_G & (OTZ_IX_G - 1u)) == 0, "power of two");
 

@@ -70,6 +70,10 @@ def main():
         else:
             print("%-10s %10.0f cyc  %5.1f%%" % (name, m, 100 * m / tot1))
     print("%-10s %10.0f cyc" % ("total", tot1))
+    t1 = np.sort(k1[:, 15])
+    print("index total per entry: p10 %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f" % tuple(t1[int(q * (n - 1))] for q in (0.1, 0.5, 0.9, 0.99, 1.0)))
+    t2 = np.sort(p[:, 15])
+    print("apply total per entry: p10 %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f" % tuple(t2[int(q * (n - 1))] for q in (0.1, 0.5, 0.9, 0.99, 1.0)))
     if k1[:, 13].any():  # (experiment builds -DOTZ_K1_EXP=...: trips of the walk loops per entry)
         print("stepsA#    %10.1f\nstepsB#    %10.1f" % (k1[:, 13].mean(), k1[:, 14].mean()))
     oz.shutdown()
