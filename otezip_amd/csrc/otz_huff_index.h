@@ -654,7 +654,9 @@ struct otz_k1_ws {
 #endif
 #define OTZ_K1_HALT 0x80000000u
 #define OTZ_K1_MERGE 0x40000000u
+#ifndef OTZ_K1_YOUNG
 #define OTZ_K1_YOUNG 768u // bits: a guessed chain that stops in the first so many bits of its segment starts over
+#endif
 template <bool SPEC, bool EARLY, bool YOUNG>
 OTZ_DEV void otz_k1_walk_loop(const otz_k1_lds &L, u32 lb, otz_k1_ws &W, u32 pend, u32 s, u32 lim2, u32 ncap, otz_ix_item *rows,
 	const otz_ix_item *rowsA, u64 bmA, u32 nckA) {

@@ -69,7 +69,9 @@ struct otz_ix_item {
 // Geometry of the index kernel's speculation (otz_huff_index.h): a span of the input is cut into 64
 // segments of S bits, one per lane, S a multiple of 32 between OTZ_K1_SMIN and OTZ_K1_SMAX.
 #define OTZ_K1_SMIN 256u
+#ifndef OTZ_K1_SMAX
 #define OTZ_K1_SMAX 4096u
+#endif
 OTZ_DEV u32 otz_k1_seg_bits(u64 span_bits) {
 	u64 s = (((span_bits + 63u) >> 6) + 31u) & ~(u64)31u;
 	return s < OTZ_K1_SMIN ? OTZ_K1_SMIN : s > OTZ_K1_SMAX ? OTZ_K1_SMAX : (u32)s;
