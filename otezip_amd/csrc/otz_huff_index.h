@@ -606,8 +606,21 @@ OTZ_DEV u32 otz_k1_classify(const otz_k1_lds &L, u32 lb, u32 u, u32 limit) {
 
 // Checkpoint (row r, this lane) of a walk's rows, [row][lane], 512 bytes a row.  The address is the rows' base (the
 // same in every lane: scalar registers) plus a 32-bit byte offset -- no 64-bit per-lane index arithmetic.
+// OTZ_K1_ROWS_LM: the rows LANE-major instead -- a lane's checkpoints one after the other (8 bytes each, `cap` of
+// them per lane), so that the eight checkpoints a lane notes in a row of time fill one 64-byte line instead of
+// touching eight.
+#ifndef OTZ_K1_ROWS_LM
+#define OTZ_K1_ROWS_LM 0
+#endif
+#if OTZ_K1_ROWS_LM
+#define OTZ_K1_RSHIFT 3u
+OTZ_DEV u32 otz_k1_lane_off(u32 cap) { return 8u * cap * otz_opaque (otz_lane ()); }
+#else
+#define OTZ_K1_RSHIFT 9u
+OTZ_DEV u32 otz_k1_lane_off(u32 cap) { return 8u * otz_opaque (otz_lane ()); }
+#endif
 OTZ_DEV const otz_ix_item *otz_k1_row(const otz_ix_item *rows, u32 r, u32 lane8) {
-	return reinterpret_cast<const otz_ix_item *> (reinterpret_cast<const u8 *> (rows) + ((r << 9) + lane8));
+	return reinterpret_cast<const otz_ix_item *> (reinterpret_cast<const u8 *> (rows) + ((r << OTZ_K1_RSHIFT) + lane8));
 }
 
 #ifdef OTZ_K1_EXP
@@ -654,13 +667,20 @@ struct otz_k1_ws {
 #endif
 #define OTZ_K1_HALT 0x80000000u
 #define OTZ_K1_MERGE 0x40000000u
+#ifndef OTZ_K1_TOUCH
+#define OTZ_K1_TOUCH 0 // 1: walk A asks for the next piece's cache lines while it walks this one (measured twice: no faster -- a trip is queueing in the CU's memory path, not DRAM latency)
+#endif
+#ifndef OTZ_K1_ACC_BATCH
+#define OTZ_K1_ACC_BATCH 16u // rows of walk A whose loads are in flight together at acceptance
+#endif
 #ifndef OTZ_K1_YOUNG
 #define OTZ_K1_YOUNG 768u // bits: a guessed chain that stops in the first so many bits of its segment starts over
 #endif
 template <bool SPEC, bool EARLY, bool YOUNG>
 OTZ_DEV void otz_k1_walk_loop(const otz_k1_lds &L, u32 lb, otz_k1_ws &W, u32 pend, u32 s, u32 lim2, u32 ncap, otz_ix_item *rows,
-	const otz_ix_item *rowsA, u64 bmA, u32 nckA) {
-	const u32 lane8 = 8u * otz_opaque (otz_lane ());
+	const otz_ix_item *rowsA, u64 bmA, u32 nckA, u32 capA) {
+	const u32 lane8 = otz_k1_lane_off (ncap / OTZ_IX_G);       // this walk's rows
+	const u32 lane8A = SPEC ? lane8 : otz_k1_lane_off (capA);  // walk A's rows (walk B reads them)
 	u32 u = W.alive ? W.u : OTZ_K1_HALT;
 	u32 bytes = W.bytes, cnt = W.cnt, first = W.first;
 	u64 bm = W.bm;
@@ -697,7 +717,7 @@ OTZ_DEV void otz_k1_walk_loop(const otz_k1_lds &L, u32 lb, otz_k1_ws &W, u32 pen
 		if (!SPEC) {
 			while (W.cpos < u) { // (rare: passed a checkpoint of walk A without landing on it)
 				W.c++;
-				W.cpos = W.c < nckA ? otz_k1_row (rowsA, W.c, lane8)->bit : OTZ_K1_NONE;
+				W.cpos = W.c < nckA ? otz_k1_row (rowsA, W.c, lane8A)->bit : OTZ_K1_NONE;
 			}
 			hit = W.cpos == u;
 			if (EARLY) { // the early token starts of walk A
@@ -721,7 +741,7 @@ OTZ_DEV void otz_k1_walk_loop(const otz_k1_lds &L, u32 lb, otz_k1_ws &W, u32 pen
 		}
 		if ((++trip & 3u) == 0) {
 			if (pk.bit != OTZ_K1_NONE) {
-				*reinterpret_cast<otz_ix_item *> (reinterpret_cast<u8 *> (rows) + (((cnt & ~(OTZ_IX_G - 1u)) << 6) + lane8)) = pk;
+				*reinterpret_cast<otz_ix_item *> (reinterpret_cast<u8 *> (rows) + (((cnt / OTZ_IX_G) << OTZ_K1_RSHIFT) + lane8)) = pk;
 				pk.bit = OTZ_K1_NONE;
 			}
 		}
@@ -731,7 +751,7 @@ OTZ_DEV void otz_k1_walk_loop(const otz_k1_lds &L, u32 lb, otz_k1_ws &W, u32 pen
 			k.bit = u;
 			k.out = bytes;
 			// (row cnt / G, 512 bytes a row: cnt is a multiple of G here)
-			*reinterpret_cast<otz_ix_item *> (reinterpret_cast<u8 *> (rows) + ((cnt << 6) + lane8)) = k;
+			*reinterpret_cast<otz_ix_item *> (reinterpret_cast<u8 *> (rows) + (((cnt / OTZ_IX_G) << OTZ_K1_RSHIFT) + lane8)) = k;
 		}
 #endif
 #if OTZ_K1_SLIDE
@@ -794,7 +814,7 @@ OTZ_DEV void otz_k1_walk_loop(const otz_k1_lds &L, u32 lb, otz_k1_ws &W, u32 pen
 	}
 #if OTZ_K1_PAIRS
 	if (pk.bit != OTZ_K1_NONE) { // (at most three steps old: the count is still in its row)
-		*reinterpret_cast<otz_ix_item *> (reinterpret_cast<u8 *> (rows) + (((cnt & ~(OTZ_IX_G - 1u)) << 6) + lane8)) = pk;
+		*reinterpret_cast<otz_ix_item *> (reinterpret_cast<u8 *> (rows) + (((cnt / OTZ_IX_G) << OTZ_K1_RSHIFT) + lane8)) = pk;
 	}
 #endif
 #ifdef OTZ_K1_EXP
@@ -907,7 +927,7 @@ OTZ_DEV void otz_k1_stage_piece(otz_k1_lds &L, const u8 *in, u32 n_in, u32 rb, u
 // Ends with every lane's W.exit set.
 template <bool SPEC>
 OTZ_DEV void otz_k1_walk(otz_k1_lds &L, const u8 *in, u32 n_in, u32 rb, u32 sb, otz_k1_ws &W, bool run, u32 start, u32 s, u32 e,
-	u32 ncap, otz_ix_item *rows, const otz_ix_item *rowsA, u64 bmA, u32 nckA, u32 firstA, u32 *first, u32 *jm, u32 *offA) {
+	u32 ncap, otz_ix_item *rows, const otz_ix_item *rowsA, u64 bmA, u32 nckA, u32 capA, u32 firstA, u32 *first, u32 *jm, u32 *offA) {
 	const u32 lane = otz_lane ();
 	const u32 limit = otz_k1_limit (n_in, rb, sb);
 	// a token that starts in front of e ends in front of e + 48: the clamp changes nothing for
@@ -928,7 +948,7 @@ OTZ_DEV void otz_k1_walk(otz_k1_lds &L, const u8 *in, u32 n_in, u32 rb, u32 sb, 
 	W.stage_cyc = 0;
 #endif
 	if (!SPEC) {
-		W.cpos = run && nckA > 1u ? otz_k1_row (rowsA, 1u, 8u * otz_opaque (lane))->bit : OTZ_K1_NONE;
+		W.cpos = run && nckA > 1u ? otz_k1_row (rowsA, 1u, otz_k1_lane_off (capA))->bit : OTZ_K1_NONE;
 	}
 	const u32 npieces = (e + OTZ_K1_P - 1u) / OTZ_K1_P;
 	for (u32 k = 0; k < npieces; k++) {
@@ -956,6 +976,20 @@ OTZ_DEV void otz_k1_walk(otz_k1_lds &L, const u8 *in, u32 n_in, u32 rb, u32 sb, 
 #ifdef OTZ_K1_EXP
 		W.stage_cyc += (u32) (otz_cycles () - exp_s0);
 #endif
+#if OTZ_K1_TOUCH
+		// The next piece's two cache lines are asked for now (a byte of each): under load a first touch of global
+		// memory is 6-7 thousand cycles, and the walk of this piece is time enough for them to reach the L2.
+		u32 touch0 = 0, touch1 = 0;
+		if (SPEC && k + 1u < npieces) {
+			const int64_t nb = otz_k1_slot0 (rb, sb) + (int64_t) ((k + 1u) * (OTZ_K1_P / 8u));
+			const int64_t last = (int64_t)n_in - 1;
+			const int64_t t0 = nb < 0 ? 0 : nb > last ? last : nb, t1 = nb + 64 < 0 ? 0 : nb + 64 > last ? last : nb + 64;
+			if (n_in != 0) {
+				touch0 = in[t0];
+				touch1 = in[t1];
+			}
+		}
+#endif
 		if (SPEC && k == 0) {
 			// the warm-up: nothing is counted or noted, and a guess that runs into a code it cannot take moves on a bit
 			u32 u = W.u;
@@ -975,13 +1009,17 @@ OTZ_DEV void otz_k1_walk(otz_k1_lds &L, const u8 *in, u32 n_in, u32 rb, u32 sb, 
 		}
 		if (k == 0) {
 			const u32 pe = s + 64u < pend ? s + 64u : pend;
-			otz_k1_walk_loop<SPEC, true, SPEC> (L, lb, W, pe, s, lim2, ncap, rows, rowsA, bmA, nckA);
+			otz_k1_walk_loop<SPEC, true, SPEC> (L, lb, W, pe, s, lim2, ncap, rows, rowsA, bmA, nckA, capA);
 		}
 		if (SPEC && k * OTZ_K1_P < s + OTZ_K1_YOUNG) {
 			const u32 py = s + OTZ_K1_YOUNG < pend ? s + OTZ_K1_YOUNG : pend;
-			otz_k1_walk_loop<SPEC, false, true> (L, lb, W, py, s, lim2, ncap, rows, rowsA, bmA, nckA);
+			otz_k1_walk_loop<SPEC, false, true> (L, lb, W, py, s, lim2, ncap, rows, rowsA, bmA, nckA, capA);
 		}
-		otz_k1_walk_loop<SPEC, false, false> (L, lb, W, pend, s, lim2, ncap, rows, rowsA, bmA, nckA);
+		otz_k1_walk_loop<SPEC, false, false> (L, lb, W, pend, s, lim2, ncap, rows, rowsA, bmA, nckA, capA);
+#if OTZ_K1_TOUCH
+		otz_consume (touch0);
+		otz_consume (touch1);
+#endif
 		// the lanes that stopped in this piece: how their walk ends
 		if (otz_ballot (W.halted) != 0) {
 			if (W.halted) {
@@ -1220,7 +1258,7 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 			// ---- walk A
 			otz_k1_ws A;
 			u32 firstA = OTZ_K1_NONE, dummy0 = 0, dummy1 = 0;
-			otz_k1_walk<true> (L, in, n_in, rb, S / 8u, A, true, lane ? s - OTZ_K1_WARM : s, s, e, rowsA_cap * OTZ_IX_G, rowsA, rowsA, 0, 0, 0, &firstA, &dummy0, &dummy1);
+			otz_k1_walk<true> (L, in, n_in, rb, S / 8u, A, true, lane ? s - OTZ_K1_WARM : s, s, e, rowsA_cap * OTZ_IX_G, rowsA, rowsA, 0, 0, rowsA_cap, 0, &firstA, &dummy0, &dummy1);
 			const u32 nckA = (A.cnt + OTZ_IX_G - 1u) / OTZ_IX_G; // checkpoint rows in front of tokens walk A took
 #ifdef OTZ_K1_EXP
 			exp_steps[0] += otz_wave_max_u32 (A.steps);
@@ -1250,7 +1288,7 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 					OTZ_K1_COUNT (8);
 					otz_k1_ws W;
 					u32 unused = 0, j = 0, ob = 0;
-					otz_k1_walk<false> (L, in, n_in, rb, S / 8u, W, rewalk, nt, s, e, rowsB_cap * OTZ_IX_G, rowsB, rowsA, A.bm, nckA, firstA, &unused, &j, &ob);
+					otz_k1_walk<false> (L, in, n_in, rb, S / 8u, W, rewalk, nt, s, e, rowsB_cap * OTZ_IX_G, rowsB, rowsA, A.bm, nckA, rowsA_cap, firstA, &unused, &j, &ob);
 					if (rewalk) {
 						const bool early = W.merged && W.cpos != W.u;
 						nB = W.cnt;
@@ -1259,7 +1297,7 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 						onA = W.merged;
 						mp = W.merged ? W.u : OTZ_K1_NONE;
 						jm = early ? j : W.c * OTZ_IX_G;
-						offA = early ? ob : onA ? otz_k1_row (rowsA, W.c, 8u * otz_opaque (lane))->out : 0u;
+						offA = early ? ob : onA ? otz_k1_row (rowsA, W.c, otz_k1_lane_off (rowsA_cap))->out : 0u;
 						exit_cur = onA ? A.exit : W.exit;
 					}
 				}
@@ -1341,7 +1379,7 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 						otz_ix_item t[4];
 #pragma unroll
 						for (u32 k = 0; k < 4u; k++) {
-							t[k] = *otz_k1_row (rowsB, acc && r0 + k < nB_items ? r0 + k : 0u, 8u * otz_opaque (lane));
+							t[k] = *otz_k1_row (rowsB, acc && r0 + k < nB_items ? r0 + k : 0u, otz_k1_lane_off (rowsB_cap));
 						}
 #pragma unroll
 						for (u32 k = 0; k < 4u; k++) {
@@ -1360,18 +1398,18 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 					it.out = obase + bytesB;
 					dst[nB_items] = it;
 				}
-				for (u32 r0 = 1; r0 < rowsA_cap; r0 += 8u) {
+				for (u32 r0 = 1; r0 < rowsA_cap; r0 += OTZ_K1_ACC_BATCH) {
 					if (otz_ballot (acc && tailA && r0 < nckA) == 0) {
 						break; // (walk A's paths are shorter than that)
 					}
-					otz_ix_item t[8];
+					otz_ix_item t[OTZ_K1_ACC_BATCH];
 #pragma unroll
-					for (u32 k = 0; k < 8u; k++) {
+					for (u32 k = 0; k < OTZ_K1_ACC_BATCH; k++) {
 						const u32 r = r0 + k;
-						t[k] = *otz_k1_row (rowsA, acc && tailA && r >= rA0 && r < nckA ? r : 0u, 8u * otz_opaque (lane));
+						t[k] = *otz_k1_row (rowsA, acc && tailA && r >= rA0 && r < nckA ? r : 0u, otz_k1_lane_off (rowsA_cap));
 					}
 #pragma unroll
-					for (u32 k = 0; k < 8u; k++) {
+					for (u32 k = 0; k < OTZ_K1_ACC_BATCH; k++) {
 						const u32 r = r0 + k;
 						if (acc && tailA && r >= rA0 && r < nckA) {
 							otz_ix_item it = t[k];
