@@ -60,6 +60,9 @@ static_assert (OTZ_A_RES_LANES <= OTZ_A_NT && OTZ_A_RES_LANES % 64u == 0, "whole
 #ifndef OTZ_A_SLIDE
 #define OTZ_A_SLIDE 0 // 1: the placement loop carries its stage words from step to step (measured: no faster)
 #endif
+#ifndef OTZ_A_FAR_WIDE
+#define OTZ_A_FAR_WIDE 1 // a copy from the entry's output in global memory reads 16 bytes in one load
+#endif
 #ifndef OTZ_A_DECIDE_AHEAD
 #define OTZ_A_DECIDE_AHEAD 1 // a round's size is decided a round ahead (two barriers fewer per round)
 #endif
@@ -547,29 +550,38 @@ OTZ_DEV void otz_far_copies(otz_apply_lds &L, const otz_job &J, u32 p0, const u1
 			if (far) {
 				n = n < (u32)-si ? n : (u32)-si; // (a step does not straddle rbuf[0])
 			}
-			u32 s0, s1, s2, s3, s4;
-			u32 q;
-			if (far) {
-				const u8 *g = J.out + (p0 + (u32)si);
-				const u32 *gp = reinterpret_cast<const u32 *> ((uintptr_t)g & ~(uintptr_t)3);
-				q = (u32) (uintptr_t)g & 3u;
-				const u32 span = q + n; // 1..19: only the words that hold bytes of the source (they lie inside the entry's output)
-				s0 = otz_ldg32 (gp);
-				s1 = span > 4u ? otz_ldg32 (gp + 1) : 0u;
-				s2 = span > 8u ? otz_ldg32 (gp + 2) : 0u;
-				s3 = span > 12u ? otz_ldg32 (gp + 3) : 0u;
-				s4 = span > 16u ? otz_ldg32 (gp + 4) : 0u;
+			u64 lo, hi;
+			const u32 gpos = p0 + (u32)si; // (far: where the source starts in the entry's output)
+			if (far && OTZ_A_FAR_WIDE && gpos + 16u <= J.out_cap) {
+				// one 16-byte load at the source's own byte address (the buffer reaches that far; what lies behind the
+				// n bytes is not used): a wavefront's copies come from 64 different places, and what a load costs in the
+				// CU's memory path is the lines it touches -- one or two here, five with a word at a time
+				otz_ldg16u (J.out + gpos, &lo, &hi);
 			} else {
-				const u32 *sp = reinterpret_cast<const u32 *> (&L.rbuf[(u32)si & ~3u]);
-				q = (u32)si & 3u;
-				s0 = sp[0];
-				s1 = sp[1];
-				s2 = sp[2];
-				s3 = sp[3];
-				s4 = sp[4];
+				u32 s0, s1, s2, s3, s4;
+				u32 q;
+				if (far) {
+					const u8 *g = J.out + gpos;
+					const u32 *gp = reinterpret_cast<const u32 *> ((uintptr_t)g & ~(uintptr_t)3);
+					q = (u32) (uintptr_t)g & 3u;
+					const u32 span = q + n; // 1..19: only the words that hold bytes of the source (they lie inside the entry's output)
+					s0 = otz_ldg32 (gp);
+					s1 = span > 4u ? otz_ldg32 (gp + 1) : 0u;
+					s2 = span > 8u ? otz_ldg32 (gp + 2) : 0u;
+					s3 = span > 12u ? otz_ldg32 (gp + 3) : 0u;
+					s4 = span > 16u ? otz_ldg32 (gp + 4) : 0u;
+				} else {
+					const u32 *sp = reinterpret_cast<const u32 *> (&L.rbuf[(u32)si & ~3u]);
+					q = (u32)si & 3u;
+					s0 = sp[0];
+					s1 = sp[1];
+					s2 = sp[2];
+					s3 = sp[3];
+					s4 = sp[4];
+				}
+				lo = otz_alignbyte (s1, s0, q) | ((u64)otz_alignbyte (s2, s1, q) << 32);
+				hi = otz_alignbyte (s3, s2, q) | ((u64)otz_alignbyte (s4, s3, q) << 32);
 			}
-			const u64 lo = otz_alignbyte (s1, s0, q) | ((u64)otz_alignbyte (s2, s1, q) << 32);
-			const u64 hi = otz_alignbyte (s3, s2, q) | ((u64)otz_alignbyte (s4, s3, q) << 32);
 			otz_a_put (L, o, lo, hi, n);
 			o += n;
 			si += (int)n;

@@ -156,6 +156,14 @@ OTZ_DEV u32 otz_ld32u(const void *p) {
 OTZ_DEV u32 otz_ldg32(const void *p) {
 	return *reinterpret_cast<const __attribute__ ((address_space (1))) u32 *> (reinterpret_cast<uintptr_t> (p));
 }
+// 16 bytes of global memory at any byte address, said to be global likewise (one global_load_dwordx4).
+typedef u32 otz_v4u __attribute__ ((ext_vector_type (4)));
+typedef otz_v4u otz_v4u_any __attribute__ ((aligned (1)));
+OTZ_DEV void otz_ldg16u(const void *p, u64 *lo, u64 *hi) {
+	const otz_v4u v = *reinterpret_cast<const __attribute__ ((address_space (1))) otz_v4u_any *> (reinterpret_cast<uintptr_t> (p));
+	*lo = (u64)v.x | ((u64)v.y << 32);
+	*hi = (u64)v.z | ((u64)v.w << 32);
+}
 OTZ_DEV void otz_st64u(void *p, u64 v) { __builtin_memcpy (p, &v, 8); }
 OTZ_DEV void otz_st32u(void *p, u32 v) { __builtin_memcpy (p, &v, 4); }
 OTZ_DEV void otz_st16u(void *p, u16 v) { __builtin_memcpy (p, &v, 2); }

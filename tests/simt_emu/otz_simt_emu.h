@@ -218,6 +218,10 @@ OTZ_DEV u32 otz_ld32u(const void *p) {
 	return v;
 }
 OTZ_DEV u32 otz_ldg32(const void *p) { return *reinterpret_cast<const u32 *> (p); }
+OTZ_DEV void otz_ldg16u(const void *p, u64 *lo, u64 *hi) {
+	memcpy (lo, p, 8);
+	memcpy (hi, static_cast<const u8 *> (p) + 8, 8);
+}
 OTZ_DEV void otz_st64u(void *p, u64 v) { memcpy (p, &v, 8); }
 OTZ_DEV void otz_st32u(void *p, u32 v) { memcpy (p, &v, 4); }
 OTZ_DEV void otz_st16u(void *p, u16 v) { memcpy (p, &v, 2); }
