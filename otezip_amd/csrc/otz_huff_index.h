@@ -671,7 +671,7 @@ struct otz_k1_ws {
 #define OTZ_K1_TOUCH 0 // 1: walk A asks for the next piece's cache lines while it walks this one (measured twice: no faster -- a trip is queueing in the CU's memory path, not DRAM latency)
 #endif
 #ifndef OTZ_K1_ACC_BATCH
-#define OTZ_K1_ACC_BATCH 16u // rows of walk A whose loads are in flight together at acceptance
+#define OTZ_K1_ACC_BATCH 16u // rows of walk A whose loads are in flight together at acceptance (even)
 #endif
 #ifndef OTZ_K1_YOUNG
 #define OTZ_K1_YOUNG 768u // bits: a guessed chain that stops in the first so many bits of its segment starts over
@@ -1408,14 +1408,28 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 						const u32 r = r0 + k;
 						t[k] = *otz_k1_row (rowsA, acc && tailA && r >= rA0 && r < nckA ? r : 0u, otz_k1_lane_off (rowsA_cap));
 					}
+					// (two items per store where a lane has both: its items lie one behind the other, and what a store
+					// costs in the CU's memory path is the lines it touches -- 64 lanes, 64 places -- not its width)
 #pragma unroll
-					for (u32 k = 0; k < OTZ_K1_ACC_BATCH; k++) {
+					for (u32 k = 0; k < OTZ_K1_ACC_BATCH; k += 2u) {
 						const u32 r = r0 + k;
-						if (acc && tailA && r >= rA0 && r < nckA) {
-							otz_ix_item it = t[k];
-							it.bit += bit0;
-							it.out += obase + bytesB - offA;
-							dst[nB_items + 1u + r - rA0] = it;
+						const bool v0 = acc && tailA && r >= rA0 && r < nckA, v1 = acc && tailA && r + 1u >= rA0 && r + 1u < nckA;
+						otz_ix_item i0 = t[k], i1 = t[k + 1u];
+						i0.bit += bit0;
+						i0.out += obase + bytesB - offA;
+						i1.bit += bit0;
+						i1.out += obase + bytesB - offA;
+						if (v0 && v1) {
+							otz_u4 w;
+							w.x = i0.bit;
+							w.y = i0.out;
+							w.z = i1.bit;
+							w.w = i1.out;
+							otz_st16 (&dst[nB_items + 1u + r - rA0], w);
+						} else if (v0) {
+							dst[nB_items + 1u + r - rA0] = i0;
+						} else if (v1) {
+							dst[nB_items + 1u + (r + 1u) - rA0] = i1;
 						}
 					}
 				}
