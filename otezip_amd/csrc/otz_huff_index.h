@@ -1128,6 +1128,10 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 		const u32 hb = (u32) (abs_bit >> 3);
 		{
 			const otz_u4 v = otz_k1_ld16 (in, n_in, (int64_t)hb + 16 * (int64_t)lane);
+			otz_u4 t = { 0, 0, 0, 0 };
+			if (lane < 2u) { // (asked for together with the first: one trip to memory, not two)
+				t = otz_k1_ld16 (in, n_in, (int64_t)hb + 1024 + 16 * (int64_t)lane);
+			}
 			otz_wave_sync (); // the window of the previous span is dead from here
 			u32 *d = &L.h.hdr_w[4u * lane];
 			d[0] = v.x;
@@ -1135,7 +1139,6 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 			d[2] = v.z;
 			d[3] = v.w;
 			if (lane < 2u) {
-				const otz_u4 t = otz_k1_ld16 (in, n_in, (int64_t)hb + 1024 + 16 * (int64_t)lane);
 				u32 *d2 = &L.h.hdr_w[256u + 4u * lane];
 				d2[0] = t.x;
 				d2[1] = t.y;
