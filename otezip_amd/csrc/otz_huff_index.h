@@ -101,12 +101,10 @@ struct otz_k1_lds {
 			u8 subw[1u << OTZ_K1_LROOT]; // per root slot: index width of its sub-table (0: none)
 		} h;
 	};
-	// (behind the window: the walk's look-ahead reads two rows past it and ignores what it gets)
 	u16 lit[OTZ_K1_LLUT + OTZ_K1_DLUT]; // the literal/length table, then the distance table (OTZ_K1_DIST): one array,
 	                                    // so that a step's SECOND lookup is one load whichever table it goes to
 };
 #define OTZ_K1_DIST(L) ((L).lit + OTZ_K1_LLUT)
-static_assert (OTZ_K1_LLUT * 2u >= 2u * 256u, "two window rows of look-ahead stay inside the LDS block");
 static_assert (OTZ_K1_P != 512u || sizeof (otz_k1_lds) <= 6u * 1280u, "twenty wavefronts per CU: six 1280-byte granules of LDS each");
 
 // ------------------------------------------------------------------ wave helpers
@@ -662,14 +660,8 @@ struct otz_k1_ws {
 // raising a bit above every position in its own u (a break out of the middle of the body costs a dozen scalar
 // instructions of execution-mask bookkeeping per way out, every iteration), and a step that must not count is
 // computed and then not added.
-#ifndef OTZ_K1_SLIDE
-#define OTZ_K1_SLIDE 0 // 1: the walk loop carries its window words from step to step (measured: no faster)
-#endif
 #define OTZ_K1_HALT 0x80000000u
 #define OTZ_K1_MERGE 0x40000000u
-#ifndef OTZ_K1_TOUCH
-#define OTZ_K1_TOUCH 0 // 1: walk A asks for the next piece's cache lines while it walks this one (measured twice: no faster -- a trip is queueing in the CU's memory path, not DRAM latency)
-#endif
 #ifndef OTZ_K1_ACC_BATCH
 #define OTZ_K1_ACC_BATCH 16u // rows of walk A whose loads are in flight together at acceptance (even)
 #endif
@@ -694,13 +686,6 @@ OTZ_DEV void otz_k1_walk_loop(const otz_k1_lds &L, u32 lb, otz_k1_ws &W, u32 pen
 	const bool may_restart = SPEC && YOUNG && otz_lane () != 0;
 #ifdef OTZ_K1_EXP
 	const u64 exp_t0 = otz_cycles ();
-#endif
-#if OTZ_K1_SLIDE
-	// The three window words of the token at u are carried from step to step: a token is at most 48 bits, so the
-	// next one starts in the same word or one of the next two, and the two words that may slide in are asked for
-	// BEFORE this step's lookups -- the step waits for its table entries, not for the window and then the entries.
-	u32 w0, w1, w2;
-	otz_k1_words (L, lb, u < pend ? u : pend - 1u, w0, w1, w2); // (a lane that stays out of the loop: any word of the piece)
 #endif
 	const u32 pbound = otz_k1_pair_bound (pend, lim2);
 #if OTZ_K1_PAIRS
@@ -754,14 +739,7 @@ OTZ_DEV void otz_k1_walk_loop(const otz_k1_lds &L, u32 lb, otz_k1_ws &W, u32 pen
 			*reinterpret_cast<otz_ix_item *> (reinterpret_cast<u8 *> (rows) + (((cnt / OTZ_IX_G) << OTZ_K1_RSHIFT) + lane8)) = k;
 		}
 #endif
-#if OTZ_K1_SLIDE
-		const u32 wi = u >> 5;
-		const u32 *pw = reinterpret_cast<const u32 *> (reinterpret_cast<const u8 *> (L.win) + ((otz_opaque (wi) << 8) + lb));
-		const u32 w3 = pw[192], w4 = pw[256];
-		otz_k1_step h = otz_k1_hot_w (L, w0, w1, w2, u, (cnt & (OTZ_IX_G - 1u)) != OTZ_IX_G - 1u, pbound);
-#else
 		otz_k1_step h = otz_k1_hot (L, lb, u, (cnt & (OTZ_IX_G - 1u)) != OTZ_IX_G - 1u, pbound);
-#endif
 #if OTZ_K1_PAIRS
 		if (!SPEC) {
 			// walk B does not step over a position of walk A it could land on: the second literal's start
@@ -802,15 +780,6 @@ OTZ_DEV void otz_k1_walk_loop(const otz_k1_lds &L, u32 lb, otz_k1_ws &W, u32 pen
 			cnt += adv ? ntok : 0u;
 			u = hit ? u | OTZ_K1_MERGE : bad ? u | OTZ_K1_HALT : tend;
 		}
-#if OTZ_K1_SLIDE
-		{ // (a lane that leaves the loop slides by whatever its flag bits make of this: its words are dead)
-			const u32 dw = (u >> 5) - wi;
-			const bool d1 = dw == 1u, d2 = dw >= 2u;
-			w0 = d2 ? w2 : d1 ? w1 : w0;
-			w1 = d2 ? w3 : d1 ? w2 : w1;
-			w2 = d2 ? w4 : d1 ? w3 : w2;
-		}
-#endif
 	}
 #if OTZ_K1_PAIRS
 	if (pk.bit != OTZ_K1_NONE) { // (at most three steps old: the count is still in its row)
@@ -976,20 +945,6 @@ OTZ_DEV void otz_k1_walk(otz_k1_lds &L, const u8 *in, u32 n_in, u32 rb, u32 sb, 
 #ifdef OTZ_K1_EXP
 		W.stage_cyc += (u32) (otz_cycles () - exp_s0);
 #endif
-#if OTZ_K1_TOUCH
-		// The next piece's two cache lines are asked for now (a byte of each): under load a first touch of global
-		// memory is 6-7 thousand cycles, and the walk of this piece is time enough for them to reach the L2.
-		u32 touch0 = 0, touch1 = 0;
-		if (SPEC && k + 1u < npieces) {
-			const int64_t nb = otz_k1_slot0 (rb, sb) + (int64_t) ((k + 1u) * (OTZ_K1_P / 8u));
-			const int64_t last = (int64_t)n_in - 1;
-			const int64_t t0 = nb < 0 ? 0 : nb > last ? last : nb, t1 = nb + 64 < 0 ? 0 : nb + 64 > last ? last : nb + 64;
-			if (n_in != 0) {
-				touch0 = in[t0];
-				touch1 = in[t1];
-			}
-		}
-#endif
 		if (SPEC && k == 0) {
 			// the warm-up: nothing is counted or noted, and a guess that runs into a code it cannot take moves on a bit
 			u32 u = W.u;
@@ -1016,10 +971,6 @@ OTZ_DEV void otz_k1_walk(otz_k1_lds &L, const u8 *in, u32 n_in, u32 rb, u32 sb, 
 			otz_k1_walk_loop<SPEC, false, true> (L, lb, W, py, s, lim2, ncap, rows, rowsA, bmA, nckA, capA);
 		}
 		otz_k1_walk_loop<SPEC, false, false> (L, lb, W, pend, s, lim2, ncap, rows, rowsA, bmA, nckA, capA);
-#if OTZ_K1_TOUCH
-		otz_consume (touch0);
-		otz_consume (touch1);
-#endif
 		// the lanes that stopped in this piece: how their walk ends
 		if (otz_ballot (W.halted) != 0) {
 			if (W.halted) {
