@@ -54,6 +54,10 @@ static_assert (OTZ_A_RES_LANES <= OTZ_A_NT && OTZ_A_RES_LANES % 64u == 0, "whole
 #ifndef OTZ_A_RES_PRIO
 #define OTZ_A_RES_PRIO 1
 #endif
+#ifndef OTZ_A_PLACE_V2
+#define OTZ_A_PLACE_V2 1 // the placement loop with one exit and no branches in its body (0: the loop that leaves through the execution mask).  Measured: no faster
+                         // while the kernel was bound by dependent latencies (512-lane workgroups); -1.2 % of the step now that it follows its instruction count
+#endif
 #ifndef OTZ_A_FAR_WIDE
 #define OTZ_A_FAR_WIDE 1 // a copy from the entry's output in global memory reads 16 bytes in one load
 #endif
@@ -322,6 +326,58 @@ OTZ_DEV u32 otz_place_items(otz_apply_lds &L, bool active, u32 s_bit, u32 e_bit,
 	u32 nm = 0;
 	u32 k0 = 0, k1 = 0, k2 = 0, k3 = 0; // the matches' destinations, newest in the low half of k0
 	u32 farm = 0;                       // bit k: the source of the k-th newest match starts before rbuf[0]
+#if OTZ_A_PLACE_V2
+	// One exit test and no way out of the middle of the body: a lane that has to stop raises a bit above every
+	// position in its own `pos` (1: the index and the stream disagree, 2: distance beyond the output start).  The
+	// distance entry is looked up for every lane -- a literal reads some entry and ignores it: a branch around the
+	// lookup would cost more than the lookup, and every step has both kinds.
+	u32 pos = active ? s_bit : 0xC0000000u;
+	for (u32 i = 0; i < OTZ_IX_G && pos < e_bit; i++) {
+		const u32 *wp = &L.stage_w[otz_opaque (pos >> 5)];
+		const u32 w0 = wp[0], w1 = wp[1], w2 = wp[2];
+		const u32 lo = otz_alignbit (w1, w0, pos), hi = otz_alignbit (w2, w1, pos);
+		const u32 e = otz_lut2<OTZ_LIT_ROOT> (L.lit_lut, lo);
+		const u32 len = e & 15u, kind = (e >> 4) & 3u;
+		const bool is_lit = kind == OTZ_K_LIT, is_len = kind == OTZ_K_LEN;
+		const u32 xb = (e >> 8) & 15u;
+		const u32 val = (e >> 16) + otz_bfe (lo, len, xb); // the literal, or the match length
+		const u32 used = len + xb; // <= 20
+		const u32 db = otz_alignbit (hi, lo, used);
+		u32 d = otz_lut2<OTZ_DIST_ROOT> (L.dist_lut, db);
+		otz_touch32 (d);
+		const u32 dl = d & 15u, dxb = (d >> 8) & 15u; // dl + dxb <= 28
+		const u32 dist = (d >> 16) + otz_bfe (db, dl, dxb);
+		// (a distance beyond the output start: ref reads window bytes nobody wrote (:524): no parity, fail cleanly;
+		// anything else that is neither a literal nor a length with a distance: the index kernel validated the
+		// chain, so this is an internal error)
+		const bool ok_len = is_len && ((d >> 4) & 3u) == OTZ_K_LEN;
+		const bool beyond = ok_len && dist > p0 + ri;
+		const bool take = ok_len && !beyond;
+		if (is_lit) {
+			L.rbuf[ri] = (u8)val;
+			otz_lds_or (&L.fin[ri >> 5], 1u << (ri & 31u));
+		}
+		if (take) {
+			const u32 cd = (dist - 1u) | ((val - 3u) << 15); // the parked match
+			L.rbuf[ri] = (u8)cd;
+			L.rbuf[ri + 1u] = (u8) (cd >> 8);
+			L.rbuf[ri + 2u] = (u8) (cd >> 16);
+			k3 = otz_alignbit (k3, k2, 16);
+			k2 = otz_alignbit (k2, k1, 16);
+			k1 = otz_alignbit (k1, k0, 16);
+			k0 = (k0 << 16) | ri;
+			farm = (farm << 1) | (dist > ri ? 1u : 0u);
+			nm += 1u;
+		}
+		ri += is_lit ? 1u : take ? val : 0u;
+		pos = is_lit ? pos + len : take ? pos + used + dl + dxb : beyond ? 0x80000002u : 0x80000001u;
+	}
+	u32 err = 0;
+	if (active) {
+		err = (pos & 0x80000000u) ? pos & 3u : pos != e_bit ? 1u : 0u;
+		pos &= 0x7FFFFFFFu;
+	}
+#else
 	u32 err = 0;                        // 1: the index and the stream disagree, 2: distance beyond the output start
 	u32 pos = s_bit;
 	if (active) {
@@ -376,6 +432,7 @@ OTZ_DEV u32 otz_place_items(otz_apply_lds &L, bool active, u32 s_bit, u32 e_bit,
 			err = 1;
 		}
 	}
+#endif
 	if (err == 2u) {
 		otz_set_status (L, OZG_ST_DATA);
 	} else if (err != 0) {
