@@ -662,6 +662,9 @@ struct otz_k1_ws {
 // computed and then not added.
 #define OTZ_K1_HALT 0x80000000u
 #define OTZ_K1_MERGE 0x40000000u
+#ifndef OTZ_K1_STAGE_ALL
+#define OTZ_K1_STAGE_ALL 0 // 1: every lane stages its piece, not only the lanes that walk in it (a re-walk pass is a few lanes: -3.5 % of the kernel)
+#endif
 #ifndef OTZ_K1_ACC_BATCH
 #define OTZ_K1_ACC_BATCH 16u // rows of walk A whose loads are in flight together at acceptance (even)
 #endif
@@ -826,7 +829,7 @@ OTZ_DEV u32 otz_k1_limit(u32 n_in, u32 rb, u32 sb) {
 // for: written the obvious way -- load a chunk, store it to LDS, next chunk -- every chunk is a global-memory round
 // trip of its own (each sits behind a bounds test), five in a row per piece, and under load that was 14 % of the
 // kernel's time.  The chunks that straddle an end of the entry (one lane, in few pieces) are patched afterwards.
-OTZ_DEV void otz_k1_stage_piece(otz_k1_lds &L, const u8 *in, u32 n_in, u32 rb, u32 sb, u32 k) {
+OTZ_DEV void otz_k1_stage_piece(otz_k1_lds &L, const u8 *in, u32 n_in, u32 rb, u32 sb, u32 k, bool need) {
 	const u32 lane = otz_lane ();
 	const int64_t b = otz_k1_slot0 (rb, sb) + (int64_t) (k * (OTZ_K1_P / 8u));
 	static_assert (OTZ_K1_WROWS % 4u == 2u, "whole 16-byte loads and half of one");
@@ -835,13 +838,16 @@ OTZ_DEV void otz_k1_stage_piece(otz_k1_lds &L, const u8 *in, u32 n_in, u32 rb, u
 	bool edge = false;
 	// (a chunk that does not lie inside the entry loads the entry's first bytes instead and is zeroed afterwards:
 	// a conditional load would have to wait for the ones in flight before its registers could be cleared)
+	// need: this lane walks the piece (a re-walk pass is a few lanes: their loads touch a few lines, not 64 x 2)
 	const bool big = n_in >= 16u;
 	if (big) {
+		if (need) {
 #pragma unroll
-		for (u32 q = 0; q < NQ; q++) {
-			const int64_t off = b + 16 * (int64_t)q;
-			const bool inside = off >= 0 && off + 16 <= (int64_t)n_in;
-			v[q] = otz_ld16 (in + (inside ? off : 0));
+			for (u32 q = 0; q < NQ; q++) {
+				const int64_t off = b + 16 * (int64_t)q;
+				const bool inside = off >= 0 && off + 16 <= (int64_t)n_in;
+				v[q] = otz_ld16 (in + (inside ? off : 0));
+			}
 		}
 	} else {
 #pragma unroll
@@ -854,7 +860,7 @@ OTZ_DEV void otz_k1_stage_piece(otz_k1_lds &L, const u8 *in, u32 n_in, u32 rb, u
 	for (u32 q = 0; q < NQ; q++) {
 		const int64_t off = b + 16 * (int64_t)q;
 		const bool inside = big && off >= 0 && off + 16 <= (int64_t)n_in;
-		edge = edge || (!inside && off + 16 > 0 && off < (int64_t)n_in);
+		edge = edge || (need && !inside && off + 16 > 0 && off < (int64_t)n_in);
 	}
 #pragma unroll
 	for (u32 q = 0; q < NQ; q++) {
@@ -869,11 +875,12 @@ OTZ_DEV void otz_k1_stage_piece(otz_k1_lds &L, const u8 *in, u32 n_in, u32 rb, u
 #pragma unroll
 		for (u32 q = 0; q < NQ; q++) {
 			const int64_t off = b + 16 * (int64_t)q;
-			if (!(big && off >= 0 && off + 16 <= (int64_t)n_in) && off + 16 > 0 && off < (int64_t)n_in) {
+			if (need && !(big && off >= 0 && off + 16 <= (int64_t)n_in) && off + 16 > 0 && off < (int64_t)n_in) {
 				v[q] = otz_k1_ld16 (in, n_in, off);
 			}
 		}
 	}
+	if (need) {
 #pragma unroll
 	for (u32 q = 0; q < NQ; q++) {
 		u32 *d = &L.win[(4u * q) * 64u + lane];
@@ -883,6 +890,7 @@ OTZ_DEV void otz_k1_stage_piece(otz_k1_lds &L, const u8 *in, u32 n_in, u32 rb, u
 			d[128] = v[q].z;
 			d[192] = v[q].w;
 		}
+	}
 	}
 }
 
@@ -940,7 +948,7 @@ OTZ_DEV void otz_k1_walk(otz_k1_lds &L, const u8 *in, u32 n_in, u32 rb, u32 sb, 
 		const u64 exp_s0 = otz_cycles ();
 #endif
 		otz_wave_sync_lds (); // the previous piece (or the block prologue's scratch) is dead
-		otz_k1_stage_piece (L, in, n_in, rb, sb, k);
+		otz_k1_stage_piece (L, in, n_in, rb, sb, k, OTZ_K1_STAGE_ALL || (W.alive && W.u < pend + 64u));
 		otz_wave_sync_lds ();
 #ifdef OTZ_K1_EXP
 		W.stage_cyc += (u32) (otz_cycles () - exp_s0);
