@@ -1050,6 +1050,7 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 	u64 pc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 #ifdef OTZ_K1_EXP
 	u32 exp_steps[2] = { 0, 0 };
+	u32 exp_pro[3] = { 0, 0, 0 };
 #endif
 	u64 plast = PROF ? otz_cycles () : 0;
 	const u64 pstart = plast;
@@ -1083,6 +1084,12 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 	otz_ix_item *const rowsB = rowsA + rowsA_cap * 64u;
 
 	while (status == 0 && !ended) {
+#ifdef OTZ_K1_EXP
+		u64 exp_t = otz_cycles ();
+#define OTZ_K1_EXP_LAP(i) do { const u64 _n = otz_cycles (); exp_pro[i] += (u32) (_n - exp_t); exp_t = _n; } while (0)
+#else
+#define OTZ_K1_EXP_LAP(i) do { } while (0)
+#endif
 		// ---- block header: stage the bytes behind the current position
 		const u32 hb = (u32) (abs_bit >> 3);
 		{
@@ -1106,9 +1113,11 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 			}
 			otz_wave_sync ();
 		}
+		OTZ_K1_EXP_LAP (0); // header bytes staged
 		const u32 hp = (u32) (abs_bit & 7u);
 		u32 cl_ok = 1;
 		const otz_hdr H = otz_k1_parse_header (L, hp, total_bits - abs_bit, &cl_ok);
+		OTZ_K1_EXP_LAP (1); // header fields, code-length code
 		if (H.st != 0 || (H.btype == 2u && !cl_ok)) {
 			status = H.st != 0 ? H.st : OZG_ST_DATA;
 			break;
@@ -1180,6 +1189,7 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 			}
 			abs_bit += used;
 		}
+		OTZ_K1_EXP_LAP (2); // code lengths
 		if (rec + OTZ_IX_ITEMS_OFF + 8u > rec_limit) {
 			status = OTZ_IX_OVERFLOW;
 			break;
@@ -1530,11 +1540,14 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 		prof[10] = pstart; // (timeline diagnostics: start, end, place)
 		prof[11] = otz_cycles ();
 		prof[12] = otz_where ();
+		prof[15] = prof[11] - pstart;
 #ifdef OTZ_K1_EXP
 		prof[13] = exp_steps[0];
 		prof[14] = exp_steps[1];
+		prof[10] = exp_pro[0]; // (instead of the timeline: cycles of the block prologues' parts)
+		prof[11] = exp_pro[1];
+		prof[12] = exp_pro[2];
 #endif
-		prof[15] = prof[11] - pstart;
 	}
 	return status == OTZ_IX_OVERFLOW;
 }

@@ -14,6 +14,6 @@ for flags in "$@"; do
 	make -C otezip_amd/csrc EXTRA="$flags" 2>&1 | grep -E "error|VGPRs|Scratch" | head -2
 	for n in 10000 2000; do
 		echo "-- $n entries"
-		timeout -k 10 200 python3 tools/prof_phases.py $n 2>&1 | grep -E "hdr|tables|slots|walkA|fixpoint|accept|^total|rewalks|fix_iters|steps|per entry" | tail -14
+		timeout -k 10 200 python3 tools/prof_phases.py $n 2>&1 | grep -E "hdr|tables|slots|walkA|fixpoint|accept|^total|rewalks|fix_iters|steps|per entry|prologue" | tail -14
 	done
 done

@@ -76,6 +76,7 @@ def main():
     print("apply total per entry: p10 %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f" % tuple(t2[int(q * (n - 1))] for q in (0.1, 0.5, 0.9, 0.99, 1.0)))
     if k1[:, 13].any():  # (experiment builds -DOTZ_K1_EXP=...: trips of the walk loops per entry)
         print("stepsA#    %10.1f\nstepsB#    %10.1f" % (k1[:, 13].mean(), k1[:, 14].mean()))
+        print("prologue: header bytes staged %.0f, header + code-length code %.0f, code lengths %.0f cyc" % (k1[:, 10].mean(), k1[:, 11].mean(), k1[:, 12].mean()))
     oz.shutdown()
 
 
