@@ -691,12 +691,6 @@ OTZ_DEV void otz_k1_walk_loop(const otz_k1_lds &L, u32 lb, otz_k1_ws &W, u32 pen
 	const u64 exp_t0 = otz_cycles ();
 #endif
 	const u32 pbound = otz_k1_pair_bound (pend, lim2);
-#if OTZ_K1_PAIRS
-	otz_ix_item pk; // the lane's checkpoint that is not in memory yet
-	pk.bit = OTZ_K1_NONE;
-	pk.out = 0;
-	u32 trip = 0;
-#endif
 	while (u < pend && cnt < ncap) {
 #ifdef OTZ_K1_EXP
 		W.steps++;
@@ -717,32 +711,17 @@ OTZ_DEV void otz_k1_walk_loop(const otz_k1_lds &L, u32 lb, otz_k1_ws &W, u32 pen
 			const u32 rel = u - s;
 			bm |= rel < 64u ? (u64)1 << rel : 0u;
 		}
-#if OTZ_K1_PAIRS
-		// With two literals in some steps the lanes' token counts drift apart and SOME lane stands on a multiple of
-		// OTZ_IX_G in nearly every trip: a store instruction per trip for a handful of lanes, and the vector-memory
-		// path of the CU is what 20 wavefronts doing that wait for.  So a checkpoint is kept in registers and the
-		// wavefront stores every fourth trip, all lanes that have one (a lane makes one every four trips at most --
-		// OTZ_IX_G tokens, two per trip -- and its count is still in the same row when it is stored).
-		if ((cnt & (OTZ_IX_G - 1u)) == 0) {
-			pk.bit = u;
-			pk.out = bytes;
-		}
-		if ((++trip & 3u) == 0) {
-			if (pk.bit != OTZ_K1_NONE) {
-				*reinterpret_cast<otz_ix_item *> (reinterpret_cast<u8 *> (rows) + (((cnt / OTZ_IX_G) << OTZ_K1_RSHIFT) + lane8)) = pk;
-				pk.bit = OTZ_K1_NONE;
-			}
-		}
-#else
+		// A checkpoint in front of every OTZ_IX_G-th STEP of the lane (cnt counts steps, a step is one token or two
+		// literals): the lanes of a walk count in lockstep (but for the few that started over), so a row is stored
+		// by all of them in the same trip -- one coalesced 512-byte store -- and an item is at most OTZ_IX_G steps
+		// of the apply kernel's placement, which pairs literals at least as eagerly (otz_lz_apply.h).
 		if ((cnt & (OTZ_IX_G - 1u)) == 0) {
 			otz_ix_item k;
 			k.bit = u;
 			k.out = bytes;
-			// (row cnt / G, 512 bytes a row: cnt is a multiple of G here)
 			*reinterpret_cast<otz_ix_item *> (reinterpret_cast<u8 *> (rows) + (((cnt / OTZ_IX_G) << OTZ_K1_RSHIFT) + lane8)) = k;
 		}
-#endif
-		otz_k1_step h = otz_k1_hot (L, lb, u, (cnt & (OTZ_IX_G - 1u)) != OTZ_IX_G - 1u, pbound);
+		otz_k1_step h = otz_k1_hot (L, lb, u, true, pbound);
 #if OTZ_K1_PAIRS
 		if (!SPEC) {
 			// walk B does not step over a position of walk A it could land on: the second literal's start
@@ -762,17 +741,10 @@ OTZ_DEV void otz_k1_walk_loop(const otz_k1_lds &L, u32 lb, otz_k1_ws &W, u32 pen
 		const u32 tend = u + h.nb;
 		const bool bad = h.stop || tend > lim2;
 		const bool adv = !bad && !hit;
-		const u32 ntok = OTZ_K1_PAIRS && h.pair ? 2u : 1u;
-#if OTZ_K1_PAIRS
-		if (SPEC && EARLY) { // the second literal of a pair is a token start of this chain like any other
-			const u32 relm = u + h.l1 - s;
-			bm |= h.pair && relm < 64u ? (u64)1 << relm : 0u;
-		}
-#endif
 		if (SPEC && YOUNG) {
 			const bool again = may_restart && h.stop && tend <= lim2;
 			bytes = again ? 0u : bytes + (adv ? h.ob : 0u);
-			cnt = again ? 0u : cnt + (adv ? ntok : 0u);
+			cnt = again ? 0u : cnt + (adv ? 1u : 0u);
 			first = again ? u + 1u : first;
 			if (EARLY) {
 				bm = again ? 0u : bm;
@@ -780,15 +752,10 @@ OTZ_DEV void otz_k1_walk_loop(const otz_k1_lds &L, u32 lb, otz_k1_ws &W, u32 pen
 			u = again ? u + 1u : bad ? u | OTZ_K1_HALT : tend;
 		} else {
 			bytes += adv ? h.ob : 0u;
-			cnt += adv ? ntok : 0u;
+			cnt += adv ? 1u : 0u;
 			u = hit ? u | OTZ_K1_MERGE : bad ? u | OTZ_K1_HALT : tend;
 		}
 	}
-#if OTZ_K1_PAIRS
-	if (pk.bit != OTZ_K1_NONE) { // (at most three steps old: the count is still in its row)
-		*reinterpret_cast<otz_ix_item *> (reinterpret_cast<u8 *> (rows) + (((cnt / OTZ_IX_G) << OTZ_K1_RSHIFT) + lane8)) = pk;
-	}
-#endif
 #ifdef OTZ_K1_EXP
 	W.loop_cyc += (u32) (otz_cycles () - exp_t0);
 #endif
@@ -899,7 +866,7 @@ OTZ_DEV void otz_k1_stage_piece(otz_k1_lds &L, const u8 *in, u32 n_in, u32 rb, u
 //     their segment at a guessed position: a warm-up (tokens neither counted nor noted) up to the first token
 //     start at or behind s -- *first (OTZ_K1_NONE: none) -- then the walk proper.
 //   !SPEC (walk B): the lanes with `run`, from their true start `start` (inside the first piece); a lane that
-//     lands on one of walk A's early token starts also recounts walk A's tokens up to there (*jm tokens,
+//     lands on one of walk A's early step starts also recounts walk A's steps up to there (*jm steps,
 //     *offA bytes; firstA: walk A's first token) while that piece is still staged.
 // Ends with every lane's W.exit set.
 template <bool SPEC>
@@ -990,11 +957,14 @@ OTZ_DEV void otz_k1_walk(otz_k1_lds &L, const u8 *in, u32 n_in, u32 rb, u32 sb, 
 			// landed on one of walk A's early token starts: count walk A's tokens up to there
 			const bool early = W.merged && W.cpos != W.u;
 			if (otz_ballot (early) != 0) {
+				// (walk A's STEPS, as its early loop took them: the same lookups, the same bound for a pair)
+				const u32 pe = s + 64u < pend ? s + 64u : pend;
+				const u32 pb = otz_k1_pair_bound (pe, lim2);
 				u32 x = firstA, j = 0, ob = 0;
 				while (early && x < W.u) {
-					const otz_k1_tok tk = otz_k1_decode (L, lb, x);
-					x += tk.nbits;
-					ob += tk.obytes;
+					const otz_k1_step h = otz_k1_hot (L, lb, x, true, pb);
+					x += h.nb;
+					ob += h.ob;
 					j++;
 				}
 				if (early) {

@@ -54,10 +54,6 @@ static_assert (OTZ_A_RES_LANES <= OTZ_A_NT && OTZ_A_RES_LANES % 64u == 0, "whole
 #ifndef OTZ_A_RES_PRIO
 #define OTZ_A_RES_PRIO 1
 #endif
-#ifndef OTZ_A_PLACE_V2
-#define OTZ_A_PLACE_V2 1 // the placement loop with one exit and no branches in its body (0: the loop that leaves through the execution mask).  Measured: no faster
-                         // while the kernel was bound by dependent latencies (512-lane workgroups); -1.2 % of the step now that it follows its instruction count
-#endif
 #ifndef OTZ_A_FAR_WIDE
 #define OTZ_A_FAR_WIDE 1 // a copy from the entry's output in global memory reads 16 bytes in one load
 #endif
@@ -309,13 +305,14 @@ OTZ_DEV bool otz_a_build_tables(otz_apply_lds &L, u32 hlit, u32 hdist) {
 
 // ---------------------------------------------------------------- placement
 //
-// Lane j decodes item j: at most OTZ_IX_G tokens from stage bit s_bit up to e_bit, first
-// output byte at buffer position ri.  Literals go to their final bytes (and are marked
+// Lane j decodes item j: at most OTZ_IX_G STEPS (a step is one token, or two literals) from stage bit s_bit
+// up to e_bit, first output byte at buffer position ri.  Literals go to their final bytes (and are marked
 // final); a match is parked in the first three bytes of its own destination (23 bits:
 // distance-1 : 15, length-3 : 8 -- a match is at least three bytes long) and its destination
-// is noted.  Lanes leave the loop, and take the literal or the match branch, through the
-// execution mask (scalar instructions) -- nothing is computed for a lane and then selected
-// away -- and a step reloads its three stage words instead of sliding a window.
+// is noted.  The loop has one exit and no branch in its body (what a lane does not need is computed and
+// not used: the kernel's time follows its instruction count, and the execution-mask bookkeeping of a loop
+// that lanes leave from the middle costs more), and a step reloads its three stage words instead of
+// sliding a window.
 // Afterwards the destinations of all matches of the round are written, in stream order, to
 // `list` (buffer positions, u16): a prefix sum over the lanes' match counts gives every lane
 // its slice.  Returns the number of matches of the round.  All OTZ_A_NT work-items.
@@ -326,7 +323,6 @@ OTZ_DEV u32 otz_place_items(otz_apply_lds &L, bool active, u32 s_bit, u32 e_bit,
 	u32 nm = 0;
 	u32 k0 = 0, k1 = 0, k2 = 0, k3 = 0; // the matches' destinations, newest in the low half of k0
 	u32 farm = 0;                       // bit k: the source of the k-th newest match starts before rbuf[0]
-#if OTZ_A_PLACE_V2
 	// One exit test and no way out of the middle of the body: a lane that has to stop raises a bit above every
 	// position in its own `pos` (1: the index and the stream disagree, 2: distance beyond the output start).  The
 	// distance entry is looked up for every lane -- a literal reads some entry and ignores it: a branch around the
@@ -343,10 +339,20 @@ OTZ_DEV u32 otz_place_items(otz_apply_lds &L, bool active, u32 s_bit, u32 e_bit,
 		const u32 val = (e >> 16) + otz_bfe (lo, len, xb); // the literal, or the match length
 		const u32 used = len + xb; // <= 20
 		const u32 db = otz_alignbit (hi, lo, used);
-		u32 d = otz_lut2<OTZ_DIST_ROOT> (L.dist_lut, db);
+		// The second lookup means what the first one makes of it (as in the index kernel's walk): behind a length code
+		// the distance entry, behind a literal the entry of the NEXT token -- and if that is a literal too, and lies
+		// inside the item, the step places both.  An item is at most OTZ_IX_G steps of the index kernel's walk, which
+		// pairs literals no more eagerly than this (otz_huff_index.h), so OTZ_IX_G steps here always reach its end.
+		const u32 *lut2 = is_len ? L.dist_lut : L.lit_lut;
+		const u32 rbits = is_len ? OTZ_DIST_ROOT : OTZ_LIT_ROOT;
+		u32 d = lut2[db & ((1u << rbits) - 1u)];
+		if ((int)d < 0) { // (a link: see otz_lut2)
+			d = lut2[((d >> 16) & 0x7FFFu) + otz_bfe (db, rbits, (d >> 8) & 15u)];
+		}
 		otz_touch32 (d);
 		const u32 dl = d & 15u, dxb = (d >> 8) & 15u; // dl + dxb <= 28
 		const u32 dist = (d >> 16) + otz_bfe (db, dl, dxb);
+		const bool pair = is_lit && ((d >> 4) & 3u) == OTZ_K_LIT && dl != 0 && pos + len + dl <= e_bit;
 		// (a distance beyond the output start: ref reads window bytes nobody wrote (:524): no parity, fail cleanly;
 		// anything else that is neither a literal nor a length with a distance: the index kernel validated the
 		// chain, so this is an internal error)
@@ -355,7 +361,14 @@ OTZ_DEV u32 otz_place_items(otz_apply_lds &L, bool active, u32 s_bit, u32 e_bit,
 		const bool take = ok_len && !beyond;
 		if (is_lit) {
 			L.rbuf[ri] = (u8)val;
-			otz_lds_or (&L.fin[ri >> 5], 1u << (ri & 31u));
+			const u64 fm = (u64) (pair ? 3u : 1u) << (ri & 31u);
+			otz_lds_or (&L.fin[ri >> 5], (u32)fm);
+			if ((u32) (fm >> 32)) { // (the second literal's bit lies in the next word)
+				otz_lds_or (&L.fin[(ri >> 5) + 1u], 1u);
+			}
+		}
+		if (pair) {
+			L.rbuf[ri + 1u] = (u8) (d >> 16);
 		}
 		if (take) {
 			const u32 cd = (dist - 1u) | ((val - 3u) << 15); // the parked match
@@ -369,70 +382,14 @@ OTZ_DEV u32 otz_place_items(otz_apply_lds &L, bool active, u32 s_bit, u32 e_bit,
 			farm = (farm << 1) | (dist > ri ? 1u : 0u);
 			nm += 1u;
 		}
-		ri += is_lit ? 1u : take ? val : 0u;
-		pos = is_lit ? pos + len : take ? pos + used + dl + dxb : beyond ? 0x80000002u : 0x80000001u;
+		ri += is_lit ? (pair ? 2u : 1u) : take ? val : 0u;
+		pos = is_lit ? pos + len + (pair ? dl : 0u) : take ? pos + used + dl + dxb : beyond ? 0x80000002u : 0x80000001u;
 	}
 	u32 err = 0;
 	if (active) {
 		err = (pos & 0x80000000u) ? pos & 3u : pos != e_bit ? 1u : 0u;
 		pos &= 0x7FFFFFFFu;
 	}
-#else
-	u32 err = 0;                        // 1: the index and the stream disagree, 2: distance beyond the output start
-	u32 pos = s_bit;
-	if (active) {
-		for (u32 i = 0; i < OTZ_IX_G; i++) {
-			if (pos >= e_bit) {
-				break;
-			}
-			const u32 *wp = &L.stage_w[otz_opaque (pos >> 5)];
-			const u32 w0 = wp[0], w1 = wp[1], w2 = wp[2];
-			const u32 lo = otz_alignbit (w1, w0, pos), hi = otz_alignbit (w2, w1, pos);
-			const u32 e = otz_lut2<OTZ_LIT_ROOT> (L.lit_lut, lo);
-			const u32 len = e & 15u, kind = (e >> 4) & 3u;
-			if (kind == OTZ_K_LIT) {
-				L.rbuf[ri] = (u8) (e >> 16);
-				otz_lds_or (&L.fin[ri >> 5], 1u << (ri & 31u));
-				ri += 1u;
-				pos += len;
-			} else if (kind == OTZ_K_LEN) {
-				const u32 xb = (e >> 8) & 15u;
-				const u32 val = (e >> 16) + otz_bfe (lo, len, xb);
-				const u32 used = len + xb; // <= 20
-				const u32 db = otz_alignbit (hi, lo, used);
-				const u32 d = otz_lut2<OTZ_DIST_ROOT> (L.dist_lut, db);
-				const u32 dl = d & 15u, dxb = (d >> 8) & 15u; // dl + dxb <= 28
-				if (((d >> 4) & 3u) != OTZ_K_LEN) {
-					err = 1; // (the index kernel validated the chain: an internal error)
-					break;
-				}
-				const u32 dist = (d >> 16) + otz_bfe (db, dl, dxb);
-				if (dist > p0 + ri) {
-					err = 2; // ref reads window bytes nobody wrote (:524): no parity, fail cleanly
-					break;
-				}
-				const u32 cd = (dist - 1u) | ((val - 3u) << 15); // the parked match
-				L.rbuf[ri] = (u8)cd;
-				L.rbuf[ri + 1u] = (u8) (cd >> 8);
-				L.rbuf[ri + 2u] = (u8) (cd >> 16);
-				k3 = otz_alignbit (k3, k2, 16);
-				k2 = otz_alignbit (k2, k1, 16);
-				k1 = otz_alignbit (k1, k0, 16);
-				k0 = (k0 << 16) | ri;
-				farm = (farm << 1) | (dist > ri ? 1u : 0u);
-				nm += 1u;
-				ri += val;
-				pos += used + dl + dxb;
-			} else {
-				err = 1;
-				break;
-			}
-		}
-		if (err == 0 && pos != e_bit) {
-			err = 1;
-		}
-	}
-#endif
 	if (err == 2u) {
 		otz_set_status (L, OZG_ST_DATA);
 	} else if (err != 0) {
