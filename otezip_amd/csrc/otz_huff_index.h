@@ -51,7 +51,7 @@
 
 static_assert (OTZ_K1_P % 128u == 0 && OTZ_K1_P >= 256u && OTZ_K1_WARM % 8u == 0 && OTZ_K1_WARM + 7u + 64u <= OTZ_K1_P, "a piece is a whole number of 16-byte loads; the warm-up and the early token starts lie in the first piece");
 static_assert (OTZ_K1_SMIN % 32u == 0 && OTZ_K1_SMAX % 32u == 0 && OTZ_K1_WARM + 7u + OTZ_K1_SMAX + 48u < (1u << 24), "segments are whole words; positions fit the exit word");
-static_assert ((OTZ_IX_G & (OTZ_IX_G - 1u)) == 0, "power of two");
+static_assert (OTZ_IX_G >= 2u && OTZ_IX_G <= 8u, "an item is two to eight steps");
 
 #define OTZ_K1_NONE 0xFFFFFFFFu
 #define OTZ_X_CAP 2u // exit kind: token budget of the round used up (not an error; the block goes on)
@@ -715,7 +715,7 @@ OTZ_DEV void otz_k1_walk_loop(const otz_k1_lds &L, u32 lb, otz_k1_ws &W, u32 pen
 		// literals): the lanes of a walk count in lockstep (but for the few that started over), so a row is stored
 		// by all of them in the same trip -- one coalesced 512-byte store -- and an item is at most OTZ_IX_G steps
 		// of the apply kernel's placement, which pairs literals at least as eagerly (otz_lz_apply.h).
-		if ((cnt & (OTZ_IX_G - 1u)) == 0) {
+		if (cnt % OTZ_IX_G == 0) {
 			otz_ix_item k;
 			k.bit = u;
 			k.out = bytes;
@@ -1432,7 +1432,7 @@ OTZ_DEV bool otz_index_entry(otz_k1_lds &L, const u8 *in, u32 n_in, u32 out_cap,
 						found = true;
 						break;
 					}
-					if ((ntok & (OTZ_IX_G - 1u)) == 0) {
+					if (ntok % OTZ_IX_G == 0) {
 						if (n_items + 2u > items_cap) {
 							status = OTZ_IX_OVERFLOW;
 							break;

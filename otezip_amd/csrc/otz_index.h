@@ -23,7 +23,9 @@
 
 #include "otz_simt.h"
 
-#define OTZ_IX_G 8u          // tokens per item
+#ifndef OTZ_IX_G
+#define OTZ_IX_G 8u          // steps per item (a step: one token, or two literals); at most 8
+#endif
 #define OTZ_IX_OVERFLOW 77   // head.status: index did not fit; decode with otz_inflate_entry
 #define OTZ_IX_KIND_STORED 0u
 #define OTZ_IX_KIND_HUFF 1u

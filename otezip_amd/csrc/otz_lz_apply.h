@@ -316,7 +316,7 @@ OTZ_DEV bool otz_a_build_tables(otz_apply_lds &L, u32 hlit, u32 hdist) {
 // Afterwards the destinations of all matches of the round are written, in stream order, to
 // `list` (buffer positions, u16): a prefix sum over the lanes' match counts gives every lane
 // its slice.  Returns the number of matches of the round.  All OTZ_A_NT work-items.
-static_assert (OTZ_IX_G == 8u, "eight 16-bit destinations are packed into four 32-bit registers");
+static_assert (OTZ_IX_G <= 8u, "up to eight 16-bit destinations are packed into four 32-bit registers");
 #define OTZ_A_LIST_CAP (OTZ_A_NT * OTZ_IX_G) // matches of a round, at most
 static_assert (OTZ_A_LIST_CAP * 2u <= OTZ_A_STAGE_BYTES, "the match lists of a round fit the stage buffer");
 OTZ_DEV u32 otz_place_items(otz_apply_lds &L, bool active, u32 s_bit, u32 e_bit, u32 ri, u32 p0, u16 *list, u32 *n_far) {
