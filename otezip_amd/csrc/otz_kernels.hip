@@ -48,7 +48,7 @@ static_assert (sizeof (otz_ix_head) == 32 && sizeof (otz_ix_block) == 32 && size
 #define OTZ_K1_WPE 5 // 7.6 KB of LDS admit 21 index wavefronts per CU: registers (<= 96) must not cut that to 16
 #endif
 #ifndef OTZ_K2_WGS
-#define OTZ_K2_WGS (OTZ_A_NT == 512u ? 4 : 8) // apply workgroups per CU
+#define OTZ_K2_WGS (OTZ_A_NT == 512u ? 3 : 7) // apply workgroups per CU (18 granules of LDS each; 36 with 512 work-items)
 #endif
 #ifndef OTZ_K2_WPE
 #define OTZ_K2_WPE (OTZ_K2_WGS * (int)(OTZ_A_NT / 64u) / 4)

@@ -24,18 +24,21 @@
 #ifndef OTZ_A_NT
 #define OTZ_A_NT 256u     // work-items of the apply kernel's workgroup: 256 or 512
 #endif
-// The sizes below put the workgroup's LDS at 16 allocation granules of 1280 bytes, so that eight workgroups share
-// a CU (32 wavefronts: every SIMD full at <= 64 registers).  Measured, ms per step of the benchmark on one box:
-// 512 work-items x 4 workgroups (4 KiB window, 16 KiB rounds) 2.51-2.53; 256 x 7 (2 KiB window, 8 KiB rounds)
-// 2.40-2.43; 256 x 8 with the sizes below 2.395, with 128 resolving work-items 2.34.
+// The sizes below put the workgroup's LDS at 18 allocation granules of 1280 bytes: seven workgroups share a CU (28
+// wavefronts).  Measured, ms per step of the benchmark on one box: 512 work-items x 4 workgroups (4 KiB window,
+// 16 KiB rounds) 2.51-2.53; 256 x 7 (2 KiB window, 8 KiB rounds) 2.40-2.43; 256 x 8 (1 KiB window, 7 KiB rounds: 16
+// granules) 2.395, with 128 resolving work-items 2.34 -- the choice while an item was eight tokens (256 items are
+// 7.4 KB of text).  Since an item is eight STEPS (up to 16 tokens, 36 bytes on average) 256 items are 9.2 KB and the
+// 7 KiB rounds left a fifth of the lanes without an item: 256 x 7 with 8.75 KiB rounds 1.923-1.932 against 256 x 8
+// 1.964-1.978 (the window 0.5 ... 1 KiB and the stage buffer 17 ... 18 bytes per work-item make no difference).
 #ifndef OTZ_A_RMAX
-#define OTZ_A_RMAX (OTZ_A_NT * 28u) // output bytes per round, at most (OTZ_A_NT items of <= OTZ_IX_G tokens come to about NT * 29 bytes of text)
+#define OTZ_A_RMAX (OTZ_A_NT * 35u) // output bytes per round, at most
 #endif
 #ifndef OTZ_A_WIN
 #define OTZ_A_WIN (OTZ_A_NT * 4u) // bytes before the round kept in LDS (a multiple of 16)
 #endif
 #ifndef OTZ_A_STAGE_PER
-#define OTZ_A_STAGE_PER 16u
+#define OTZ_A_STAGE_PER 18u
 #endif
 #define OTZ_A_STAGE_BYTES (OTZ_A_NT * OTZ_A_STAGE_PER) // the round's compressed bytes (16 bits a token on average; more: a shorter round), then its match lists
 #define OTZ_A_STAGE_WORDS (OTZ_A_STAGE_BYTES / 4u)
